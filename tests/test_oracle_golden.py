@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/diffputer_oracle.py) to outputs of the reference itself.
+
+The fixtures under tests/golden/ were produced by tools/make_goldens.py, which imports the
+reference's model.py / diffusion_utils.py in the build container and replays a recorded noise
+stream through them.  The reference has no tests or golden vectors of its own for this path
+(SURVEY.md §4), so these are the pins.  Tolerance: 1e-5 (BLAS summation order, libm ulp).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_noise, load_golden
+from diffputer_amd import synth
+from oracle import diffputer_oracle as orc
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b)
+    lim = atol + rtol * np.abs(b)
+    assert a.shape == b.shape
+    assert np.all(err <= lim), f"max err {err.max():.3e}, worst excess {(err - lim).max():.3e}"
+
+
+def test_schedule_matches_reference():
+    g = load_golden("schedule")
+    for S in (5, 10, 50):
+        t = orc.sigma_schedule(S)
+        ref = g[f"t_S{S}"]
+        assert t.dtype == np.float32 and t.shape == (S + 1,)
+        # fp32 pow differs by at most an ulp or two between torch/Sleef and numpy/libm
+        assert np.all(np.abs(t - ref) <= 2 * np.spacing(ref)), (t - ref)
+        assert t[-1] == 0.0
+    # values quoted in SURVEY.md §8 a7
+    t = g["t_S50"]
+    assert abs(t[0] - 79.99998474) < 1e-5 and abs(t[49] - 0.00199999963) < 1e-9
+
+
+@pytest.mark.parametrize("hid", [64, 1024])
+def test_time_embedding(hid):
+    g = load_golden(f"embedding_H{hid}")
+    sd = synth.make_weights(int(g["d_in"]), hid, int(g["wseed"]), float(g["gain"]))
+    c_noise = np.log(g["sigma"]) / np.float32(4.0)
+    close(orc.positional_embedding(c_noise, hid), g["posemb"], atol=2e-6)
+    close(orc.time_embedding(sd, c_noise), g["emb"])
+
+
+@pytest.mark.parametrize("d_in", [9, 64, 256])
+def test_denoiser_single_eval(d_in):
+    g = load_golden(f"denoiser_D{d_in}_H1024")
+    sd = synth.make_weights(d_in, 1024, int(g["wseed"]), float(g["gain"]))
+    for k, s in enumerate(g["sigma"]):
+        D, F = orc.precond(sd, g["x"][k], s, return_F=True)
+        close(F, g["F"][k])
+        close(D, g["D"][k], atol=1e-5 * max(1.0, float(s)))
+
+
+def test_sample_step():
+    g = load_golden("sample_step_D9_H64_S10")
+    sd = synth.make_weights(9, 64, int(g["wseed"]), float(g["gain"]))
+    S = int(g["S"])
+    t = orc.sigma_schedule(S)
+    for i in g["levels"]:
+        y = orc.sample_step(sd, S, int(i), t[i], t[i + 1], g[f"x_{i}"], g[f"eps_{i}"])
+        close(y, g[f"y_{i}"], atol=1e-5 * max(1.0, float(t[i])))
+    # last level (t_next = 0) returns the denoised sample itself
+    i = S - 1
+    th = np.float32(t[i] + np.float32(0.1) * t[i])
+    x_hat = g[f"x_{i}"] + np.sqrt(th * th - t[i] * t[i]) * g[f"eps_{i}"]
+    close(orc.precond(sd, x_hat, th), g[f"y_{i}"], atol=2e-6)
+
+
+def _run_impute(name, noise=None):
+    g = load_golden(name)
+    sd = synth.make_weights(int(g["d_in"]), int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+    stream = g["noise"] if "noise" in g else golden_noise(g)
+    trace = []
+    out = orc.impute_mask(sd, g["x_obs"], g["mask"], stream, int(g["S"]), int(g["R"]), trace)
+    return g, out, np.stack(trace)
+
+
+@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16",
+                                  "impute_D9_H64_S50_N8"])
+def test_impute_mask_trajectory(name):
+    g, out, trace = _run_impute(name)
+    t = orc.sigma_schedule(int(g["S"]))
+    assert trace.shape[0] == (int(g["S"]) - 1) * int(g["R"]) + 1
+    # per-iteration tolerance scales with the noise level of that iteration
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        lvl = min(int(k) // int(g["R"]), int(g["S"]) - 1)
+        close(trace[k], ref, atol=1e-5 * max(1.0, float(t[lvl])))
+    close(out, g["out"], atol=1e-5)
+    # observed cells come back bit-exactly (t_next = 0 at the last level)
+    obs = ~g["mask"]
+    assert np.array_equal(out[obs], g["x_obs"][obs])
+    assert np.array_equal(g["out"][obs], g["x_obs"][obs])
+
+
+def test_impute_mask_noise_stored_equals_regenerated():
+    g = load_golden("impute_D9_H64_S5_N8")
+    assert np.array_equal(golden_noise(g), g["noise"])
+
+
+@pytest.mark.parametrize("name", ["impute_D64_H1024_S10_N32"])
+def test_impute_mask_full_width(name):
+    g, out, trace = _run_impute(name)
+    close(out, g["out"], atol=2e-5)
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        close(trace[k], ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_estep_driver():
+    g = load_golden("estep_D9_H64_S5_T3")
+    n, d, S, R, T = (int(g[k]) for k in ("n", "d_in", "S", "R", "T"))
+    sd = synth.make_weights(d, int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+    noise = [synth.reference_noise(int(s), synth.n_draws(S, R), (n, d)) for s in g["nseeds"]]
+    mean = orc.e_step(sd, g["X"], g["mask"], noise, T, S, R)
+    close(mean, g["mean"])
+    obs = ~g["mask"]
+    close(mean[obs], g["X"][obs], atol=1e-7)
+
+
+def test_draw_count():
+    assert synth.n_draws(50, 20) == 3924        # SURVEY.md §0 [probed]
