@@ -1,0 +1,462 @@
+// libdiffputer_hip.so -- plan object, host-side sampler loop and the C ABI of include/diffputer.h.
+// gfx950 (MI355X) only.  Build: see __graft_entry__.build().
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dp_embed.h"
+#include "dp_gemm_bf16.h"
+#include "dp_gemm_f32.h"
+#include "dp_philox.h"
+#include "dp_step.h"
+#include "dp_util.h"
+
+namespace dp {
+thread_local std::string g_err;
+
+// ---- host-side float32 scalar algebra, in the reference's operation order -------------------------------------
+// (this TU is compiled with -ffp-contract=off for host code; x86-64 baseline has no fma anyway)
+struct Coef { float c_skip, c_out, c_in, c_noise; };
+static Coef precond_coef(float s) {                       // model.py:155-158 with sigma_data = 0.5 (model.py:137)
+    const float sd2 = 0.25f;
+    Coef c;
+    c.c_skip = sd2 / (s * s + sd2);
+    c.c_out = s * 0.5f / sqrtf(s * s + sd2);
+    c.c_in = 1.0f / sqrtf(sd2 + s * s);
+    c.c_noise = logf(s) / 4.0f;
+    return c;
+}
+static float churn_gamma(int num_steps) {                 // diffusion_utils.py:94 with S_churn=1, S_min=0, S_max=inf
+    const double g = std::min(1.0 / num_steps, sqrt(2.0) - 1.0);
+    return (float)g;
+}
+
+struct Level { float sigma; Coef c; };
+
+}  // namespace dp
+
+using namespace dp;
+
+struct dp_plan {
+    int d_in = 0, hid = 0, S = 0, R = 0, dtype = 0, device = 0;
+    int K1 = 0, N5 = 0;                  // padded widths of GEMM-1's K and GEMM-5's N
+    int n_levels = 0;                    // 2S-1
+    bool weights_set = false;
+    // host tables
+    std::vector<float> t, th, churn, renoise;
+    std::vector<Level> lv;               // [2i] = t_hat_i, [2i+1] = t_{i+1}
+    // device
+    void* W[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // packed weights (bf16 or f32)
+    float* B[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // biases (B[4] padded to N5; B[0] = proj.bias)
+    float *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
+    float *b_eff = nullptr;              // [(n_levels + 2), hid]; the last two rows are scratch for dp_denoise/dp_sample_step
+    float *c_noise_dev = nullptr, *pe = nullptr, *hidden = nullptr;   // [(n_levels + 2)] / [.., hid] scratch
+    size_t esize() const { return dtype == DP_DTYPE_BF16 ? 2 : 4; }
+};
+
+namespace dp {
+
+static int grid_for(int64_t n, int block = 256, int cap = 2048) {
+    int64_t g = ceil_div<int64_t>(n, block);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+// ---- GEMM dispatch ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+static int launch_bf16_cfg(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
+                           int act, int out_f32, hipStream_t st) {
+    constexpr int LDS = gemm_bf16_lds_bytes<BM, BN>();
+    const int nbn = N / BN;
+    const int64_t nwg64 = (M / BM) * nbn;
+    if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
+    const int nwg = (int)nwg64;
+#define DP_GO(ACT, OF)                                                                                              \
+    do {                                                                                                            \
+        auto kern = k_gemm_bf16<BM, BN, WM, WN, ACT, OF>;                                                           \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));        \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM* WN * 64), LDS, st, A, W, bias, out, ldo, K, nbn, nwg);         \
+    } while (0)
+    if (act && !out_f32) DP_GO(true, false);
+    else if (!act && !out_f32) DP_GO(false, false);
+    else if (!act && out_f32) DP_GO(false, true);
+    else DP_GO(true, true);
+#undef DP_GO
+    DP_LAUNCH_CHECK("k_gemm_bf16");
+    return DP_OK;
+}
+
+static int gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int ldo, int64_t M, int N, int K, int act,
+                int out_f32, hipStream_t st) {
+    if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
+        return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
+    if (dtype == DP_DTYPE_BF16) {
+        if (N % 256 == 0)
+            return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
+        return launch_bf16_cfg<256, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
+    }
+    if (dtype != DP_DTYPE_F32) return fail(DP_EINVAL, "unknown dtype %d", dtype);
+    const int nbn = N / 64;
+    const int64_t nwg = (M / 128) * nbn;
+    if (nwg > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
+    if (act) hipLaunchKernelGGL(k_gemm_f32<true>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)A, (const float*)W, bias, (float*)out, ldo, K, nbn);
+    else hipLaunchKernelGGL(k_gemm_f32<false>, dim3((unsigned)nwg), dim3(256), 0, st, (const float*)A, (const float*)W, bias, (float*)out, ldo, K, nbn);
+    DP_LAUNCH_CHECK("k_gemm_f32");
+    return DP_OK;
+}
+
+// ---- workspace -------------------------------------------------------------------------------------------------
+struct Workspace {
+    float *x_hat, *d_cur, *F;
+    void *u, *actA, *actB;
+    int64_t M, Mp;
+    size_t bytes;
+};
+static Workspace carve(const dp_plan* p, int64_t M, void* base) {
+    Workspace w;
+    w.M = M;
+    w.Mp = round_up<int64_t>(M, 256);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += round_up<size_t>(n, 256); return base ? (void*)((char*)base + o) : (void*)nullptr; };
+    w.x_hat = (float*)take((size_t)M * p->d_in * 4);
+    w.d_cur = (float*)take((size_t)M * p->d_in * 4);
+    w.F = (float*)take((size_t)w.Mp * p->N5 * 4);
+    w.u = take((size_t)w.Mp * p->K1 * p->esize());
+    w.actA = take((size_t)w.Mp * 2 * p->hid * p->esize());
+    w.actB = take((size_t)w.Mp * 2 * p->hid * p->esize());
+    w.bytes = off;
+    return w;
+}
+
+// ---- one denoiser evaluation F(u, level): five GEMMs with fused epilogues (model.py:121-128) ---------------------
+static int eval_F(const dp_plan* p, const Workspace& w, const float* b_eff_row, hipStream_t st) {
+    const int H = p->hid, dt = p->dtype;
+    int rc;
+    if ((rc = gemm(dt, w.u, p->W[0], b_eff_row, w.actA, H, w.Mp, H, p->K1, 0, 0, st))) return rc;          // proj + emb (no act)
+    if ((rc = gemm(dt, w.actA, p->W[1], p->B[1], w.actB, 2 * H, w.Mp, 2 * H, H, 1, 0, st))) return rc;      // mlp.0 + SiLU
+    if ((rc = gemm(dt, w.actB, p->W[2], p->B[2], w.actA, 2 * H, w.Mp, 2 * H, 2 * H, 1, 0, st))) return rc;  // mlp.2 + SiLU
+    if ((rc = gemm(dt, w.actA, p->W[3], p->B[3], w.actB, H, w.Mp, H, 2 * H, 1, 0, st))) return rc;          // mlp.4 + SiLU
+    if ((rc = gemm(dt, w.actB, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;         // mlp.6 -> f32
+    return DP_OK;
+}
+
+// b_eff rows [first, first+count) from c_noise_dev[first..] (model.py:122-127)
+static int compute_embedding(dp_plan* p, int first, int count, hipStream_t st) {
+    const int H = p->hid;
+    hipLaunchKernelGGL(k_posemb, dim3(grid_for((int64_t)count * H / 2)), dim3(256), 0, st, p->c_noise_dev + first, p->pe + (size_t)first * H, count, H);
+    DP_LAUNCH_CHECK("k_posemb");
+    const int waves = count * H, blocks = ceil_div(waves, 4);
+    hipLaunchKernelGGL(k_small_linear<true>, dim3(blocks), dim3(256), 0, st, p->pe + (size_t)first * H, p->te_w0, p->te_b0, (const float*)nullptr,
+                       p->hidden + (size_t)first * H, count, H, H);
+    DP_LAUNCH_CHECK("k_small_linear<silu>");
+    hipLaunchKernelGGL(k_small_linear<false>, dim3(blocks), dim3(256), 0, st, p->hidden + (size_t)first * H, p->te_w2, p->te_b2, (const float*)p->B[0],
+                       p->b_eff + (size_t)first * H, count, H, H);
+    DP_LAUNCH_CHECK("k_small_linear");
+    return DP_OK;
+}
+
+__global__ void k_set2(float* dst, float a, float b) { dst[0] = a; dst[1] = b; }
+
+static int check_plan(const dp_plan* p, bool need_weights) {
+    if (!p) return fail(DP_EINVAL, "plan is NULL");
+    if (need_weights && !p->weights_set) return fail(DP_ESTATE, "dp_plan_set_weights has not been called on this plan");
+    int dev = -1;
+    DP_HIP(hipGetDevice(&dev));
+    if (dev != p->device) return fail(DP_ESTATE, "plan belongs to device %d but device %d is current", p->device, dev);
+    return DP_OK;
+}
+
+static void free_plan_buffers(dp_plan* p) {
+    for (int i = 0; i < 5; ++i) { if (p->W[i]) (void)hipFree(p->W[i]); if (p->B[i]) (void)hipFree(p->B[i]); p->W[i] = nullptr; p->B[i] = nullptr; }
+    float** f[] = {&p->te_w0, &p->te_b0, &p->te_w2, &p->te_b2, &p->b_eff, &p->c_noise_dev, &p->pe, &p->hidden};
+    for (auto q : f) { if (*q) (void)hipFree(*q); *q = nullptr; }
+}
+
+}  // namespace dp
+
+// ================================================================================================================
+extern "C" {
+
+int dp_version(void) { return 1; }
+
+const char* dp_last_error(void) { return g_err.c_str(); }
+
+int dp_plan_create(dp_plan** out, int d_in, int hid, int num_steps, int n_resample, int dtype) {
+    if (!out) return fail(DP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (d_in < 1 || d_in > 4096) return fail(DP_EINVAL, "d_in=%d out of range [1, 4096]", d_in);
+    if (hid < 64 || hid % 64) return fail(DP_EINVAL, "hid=%d must be a positive multiple of 64", hid);
+    if (num_steps < 2 || num_steps > 100000) return fail(DP_EINVAL, "num_steps=%d must be >= 2", num_steps);
+    if (n_resample < 1) return fail(DP_EINVAL, "n_resample=%d must be >= 1", n_resample);
+    if (dtype != DP_DTYPE_F32 && dtype != DP_DTYPE_BF16) return fail(DP_EINVAL, "dtype=%d unknown", dtype);
+    dp_plan* p = new dp_plan();
+    p->d_in = d_in; p->hid = hid; p->S = num_steps; p->R = n_resample; p->dtype = dtype;
+    p->K1 = round_up(d_in, 64);
+    p->N5 = round_up(d_in, 64);
+    p->n_levels = 2 * num_steps - 1;
+    hipError_t e = hipGetDevice(&p->device);
+    if (e != hipSuccess) { delete p; return fail(DP_EHIP, "hipGetDevice failed: %s", hipGetErrorString(e)); }
+
+    // sigma schedule (diffusion_utils.py:24,27-32), float32 op by op; sigma_min = max(0.002, 0), sigma_max = min(80, inf)
+    const int S = num_steps;
+    const double rho = 7.0;
+    const float a = (float)pow(80.0, 1.0 / rho);
+    const float b = (float)(pow(0.002, 1.0 / rho) - pow(80.0, 1.0 / rho));
+    p->t.resize(S + 1);
+    for (int i = 0; i < S; ++i) {
+        const float q = (float)i / (float)(S - 1);
+        const float base = a + q * b;
+        p->t[i] = powf(base, 7.0f);
+    }
+    p->t[S] = 0.f;
+    // per-level constants of sample_step (diffusion_utils.py:94-96) and of the re-noise (:52)
+    const float gamma = churn_gamma(S);
+    p->th.resize(S); p->churn.resize(S); p->renoise.resize(S);
+    p->lv.resize(p->n_levels);
+    for (int i = 0; i < S; ++i) {
+        const float tc = p->t[i], tn = p->t[i + 1];
+        const float th = tc + gamma * tc;
+        p->th[i] = th;
+        p->churn[i] = sqrtf(th * th - tc * tc);
+        p->renoise[i] = sqrtf(tc * tc - tn * tn);
+        p->lv[2 * i] = {th, precond_coef(th)};
+        if (i < S - 1) p->lv[2 * i + 1] = {tn, precond_coef(tn)};
+    }
+    *out = p;
+    return DP_OK;
+}
+
+void dp_plan_destroy(dp_plan* p) {
+    if (!p) return;
+    free_plan_buffers(p);
+    delete p;
+}
+
+int dp_plan_set_weights(dp_plan* p, const float* const w[7], const float* const b[7], void* stream) {
+    int rc = check_plan(p, false);
+    if (rc) return rc;
+    if (!w || !b) return fail(DP_EINVAL, "w or b is NULL");
+    for (int i = 0; i < 7; ++i)
+        if (!w[i] || !b[i]) return fail(DP_EINVAL, "weight/bias %d is NULL", i);
+    hipStream_t st = (hipStream_t)stream;
+    const int H = p->hid, D = p->d_in;
+    const size_t es = p->esize();
+    const int bf = p->dtype == DP_DTYPE_BF16;
+    free_plan_buffers(p);
+    p->weights_set = false;
+    // [out, in] of the five GEMM layers and their padded shapes
+    const int rows[5] = {H, 2 * H, 2 * H, H, D}, cols[5] = {D, H, 2 * H, 2 * H, H};
+    const int rows_p[5] = {H, 2 * H, 2 * H, H, p->N5}, cols_p[5] = {p->K1, H, 2 * H, 2 * H, H};
+    for (int i = 0; i < 5; ++i) {
+        DP_HIP(hipMalloc(&p->W[i], (size_t)rows_p[i] * cols_p[i] * es));
+        DP_HIP(hipMalloc((void**)&p->B[i], (size_t)rows_p[i] * 4));
+        hipLaunchKernelGGL(k_pack_weight, dim3(grid_for((int64_t)rows_p[i] * cols_p[i])), dim3(256), 0, st, w[i], p->W[i], rows[i], cols[i],
+                           rows_p[i], cols_p[i], bf);
+        DP_LAUNCH_CHECK("k_pack_weight");
+        hipLaunchKernelGGL(k_pad_bias, dim3(grid_for(rows_p[i])), dim3(256), 0, st, b[i], p->B[i], rows[i], rows_p[i]);
+        DP_LAUNCH_CHECK("k_pad_bias");
+    }
+    const int E = p->n_levels + 2;
+    DP_HIP(hipMalloc((void**)&p->te_w0, (size_t)H * H * 4));
+    DP_HIP(hipMalloc((void**)&p->te_w2, (size_t)H * H * 4));
+    DP_HIP(hipMalloc((void**)&p->te_b0, (size_t)H * 4));
+    DP_HIP(hipMalloc((void**)&p->te_b2, (size_t)H * 4));
+    DP_HIP(hipMalloc((void**)&p->b_eff, (size_t)E * H * 4));
+    DP_HIP(hipMalloc((void**)&p->pe, (size_t)E * H * 4));
+    DP_HIP(hipMalloc((void**)&p->hidden, (size_t)E * H * 4));
+    DP_HIP(hipMalloc((void**)&p->c_noise_dev, (size_t)E * 4));
+    DP_HIP(hipMemcpyAsync(p->te_w0, w[5], (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
+    DP_HIP(hipMemcpyAsync(p->te_w2, w[6], (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
+    DP_HIP(hipMemcpyAsync(p->te_b0, b[5], (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    DP_HIP(hipMemcpyAsync(p->te_b2, b[6], (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    std::vector<float> cn(E, 0.f);
+    for (int e = 0; e < p->n_levels; ++e) cn[e] = p->lv[e].c.c_noise;
+    DP_HIP(hipMemcpyAsync(p->c_noise_dev, cn.data(), (size_t)E * 4, hipMemcpyHostToDevice, st));
+    DP_HIP(hipStreamSynchronize(st));                                 // cn is a stack-lifetime host buffer
+    if ((rc = compute_embedding(p, 0, p->n_levels, st))) return rc;
+    DP_HIP(hipStreamSynchronize(st));
+    p->weights_set = true;
+    return DP_OK;
+}
+
+size_t dp_workspace_bytes(const dp_plan* p, int64_t n_chains) {
+    if (!p || n_chains <= 0) { fail(DP_EINVAL, "dp_workspace_bytes: bad plan or n_chains"); return 0; }
+    return carve(p, n_chains, nullptr).bytes;
+}
+
+int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, int64_t n_rows, int num_trials, uint64_t seed,
+              uint64_t row_offset, int trial_offset, const float* noise, float* trace, int flags, void* workspace,
+              size_t workspace_bytes, void* stream) {
+    int rc = check_plan(p, true);
+    if (rc) return rc;
+    if (!x_obs || !mask || !out || !workspace) return fail(DP_EINVAL, "x_obs, mask, out and workspace must be non-NULL");
+    if (n_rows <= 0 || num_trials <= 0) return fail(DP_EINVAL, "n_rows=%lld and num_trials=%d must be positive", (long long)n_rows, num_trials);
+    if (trial_offset < 0 || (int64_t)trial_offset + num_trials > 65536) return fail(DP_EINVAL, "global trial index must stay below 65536");
+    if (((uintptr_t)workspace & 255) != 0) return fail(DP_EINVAL, "workspace must be 256-byte aligned");
+    const int64_t M = n_rows * num_trials;
+    Workspace w = carve(p, M, workspace);
+    if (w.bytes > workspace_bytes)
+        return fail(DP_EWORKSPACE, "workspace of %zu bytes is too small for %lld chains (need %zu)", workspace_bytes, (long long)M, w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = p->S, R = p->R, D = p->d_in, H = p->hid;
+    const int n_iter = R * (S - 1) + 1;
+
+    StepCommon c;
+    c.x_hat = w.x_hat; c.d_cur = w.d_cur; c.F = w.F; c.u = w.u;
+    c.x_obs = x_obs; c.mask = mask; c.noise = noise; c.trace = trace;
+    c.n_cells = M * D; c.n_rows = n_rows;
+    c.draw_stride = n_rows * D;
+    c.trial_stride = (int64_t)(1 + 4 * (int64_t)R * (S - 1) + 3) * c.draw_stride;
+    c.seed = seed; c.row_offset = row_offset;
+    c.D = D; c.ldF = p->N5; c.ldu = p->K1; c.u_bf16 = p->dtype == DP_DTYPE_BF16;
+    c.trial_offset = trial_offset; c.num_trials = num_trials;
+
+    // pad rows / pad columns of u stay zero for the whole call; the step kernels only write [0,M) x [0,D)
+    DP_HIP(hipMemsetAsync(w.u, 0, (size_t)w.Mp * p->K1 * p->esize(), st));
+    const int g = grid_for(c.n_cells);
+    hipLaunchKernelGGL(k_step_init, dim3(g), dim3(256), 0, st, c, p->t[0], p->churn[0], p->lv[0].c.c_in);
+    DP_LAUNCH_CHECK("k_step_init");
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int i = std::min(it / R, S - 1);
+        const int j = it - i * R;
+        const Level& l0 = p->lv[2 * i];
+        const float h = p->t[i + 1] - p->th[i];
+        if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i) * H, st))) return rc;
+        if (i < S - 1) {
+            const Level& l1 = p->lv[2 * i + 1];
+            hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
+            DP_LAUNCH_CHECK("k_step_mid");
+            if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i + 1) * H, st))) return rc;
+            const int add_re = j < R - 1;
+            const int i_next = std::min((it + 1) / R, S - 1);
+            hipLaunchKernelGGL(k_step_end, dim3(g), dim3(256), 0, st, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re,
+                               p->churn[i_next], p->lv[2 * i_next].c.c_in);
+            DP_LAUNCH_CHECK("k_step_end");
+        } else {
+            hipLaunchKernelGGL(k_step_final, dim3(grid_for(n_rows * D)), dim3(256), 0, st, c, it, l0.c.c_skip, l0.c.c_out, p->th[i], h, out,
+                               (flags & DP_ACCUMULATE) ? 1 : 0);
+            DP_LAUNCH_CHECK("k_step_final");
+        }
+    }
+    return DP_OK;
+}
+
+// Embedding rows for up to two arbitrary sigmas into the plan's scratch rows; returns their row indices.
+static int scratch_embedding(dp_plan* p, float s0, float s1, hipStream_t st) {
+    const int first = p->n_levels;
+    hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, st, p->c_noise_dev + first, precond_coef(s0).c_noise, precond_coef(s1).c_noise);
+    DP_LAUNCH_CHECK("k_set2");
+    return compute_embedding(p, first, 2, st);
+}
+
+int dp_denoise(dp_plan* p, const float* x, float sigma, float* D_out, float* F_out, int64_t n, void* workspace,
+               size_t workspace_bytes, void* stream) {
+    int rc = check_plan(p, true);
+    if (rc) return rc;
+    if (!x || !workspace || n <= 0) return fail(DP_EINVAL, "x, workspace must be non-NULL and n positive");
+    if (!(sigma > 0.f)) return fail(DP_EINVAL, "sigma must be positive");
+    if (((uintptr_t)workspace & 255) != 0) return fail(DP_EINVAL, "workspace must be 256-byte aligned");
+    Workspace w = carve(p, n, workspace);
+    if (w.bytes > workspace_bytes) return fail(DP_EWORKSPACE, "workspace of %zu bytes is too small for %lld rows (need %zu)", workspace_bytes, (long long)n, w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const Coef k = precond_coef(sigma);
+    if ((rc = scratch_embedding(p, sigma, sigma, st))) return rc;
+    DP_HIP(hipMemsetAsync(w.u, 0, (size_t)w.Mp * p->K1 * p->esize(), st));
+    const int64_t cells = n * p->d_in;
+    hipLaunchKernelGGL(k_scale_in, dim3(grid_for(cells)), dim3(256), 0, st, x, w.u, p->K1, (int)(p->dtype == DP_DTYPE_BF16), cells, p->d_in, k.c_in);
+    DP_LAUNCH_CHECK("k_scale_in");
+    if ((rc = eval_F(p, w, p->b_eff + (size_t)p->n_levels * p->hid, st))) return rc;
+    hipLaunchKernelGGL(k_precond_out, dim3(grid_for(cells)), dim3(256), 0, st, x, (const float*)w.F, p->N5, D_out, F_out, cells, p->d_in, k.c_skip, k.c_out);
+    DP_LAUNCH_CHECK("k_precond_out");
+    return DP_OK;
+}
+
+int dp_sample_step(dp_plan* p, int i, float t_cur, float t_next, const float* x_cur, const float* eps, float* x_next, int64_t n,
+                   uint64_t seed, uint64_t row_offset, uint32_t block, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_plan(p, true);
+    if (rc) return rc;
+    if (!x_cur || !x_next || !workspace || n <= 0) return fail(DP_EINVAL, "x_cur, x_next, workspace must be non-NULL and n positive");
+    if (!(t_cur > 0.f) || t_next < 0.f) return fail(DP_EINVAL, "need t_cur > 0 and t_next >= 0");
+    const bool heun = i < p->S - 1;                                   // diffusion_utils.py:104
+    if (heun && !(t_next > 0.f)) return fail(DP_EINVAL, "t_next must be positive at a Heun level (i < num_steps-1)");
+    if (((uintptr_t)workspace & 255) != 0) return fail(DP_EINVAL, "workspace must be 256-byte aligned");
+    Workspace w = carve(p, n, workspace);
+    if (w.bytes > workspace_bytes) return fail(DP_EWORKSPACE, "workspace of %zu bytes is too small for %lld rows (need %zu)", workspace_bytes, (long long)n, w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const float gamma = churn_gamma(p->S);
+    const float th = t_cur + gamma * t_cur;
+    const float churn = sqrtf(th * th - t_cur * t_cur);
+    const float h = t_next - th;
+    const Coef k0 = precond_coef(th);
+    const Coef k1 = heun ? precond_coef(t_next) : k0;
+    if ((rc = scratch_embedding(p, th, heun ? t_next : th, st))) return rc;
+    const int bf = p->dtype == DP_DTYPE_BF16, D = p->d_in;
+    const int64_t cells = n * D;
+    const int g = grid_for(cells);
+    DP_HIP(hipMemsetAsync(w.u, 0, (size_t)w.Mp * p->K1 * p->esize(), st));
+    hipLaunchKernelGGL(k_churn, dim3(g), dim3(256), 0, st, x_cur, eps, w.x_hat, w.u, p->K1, bf, cells, D, churn, k0.c_in, seed, row_offset, block);
+    DP_LAUNCH_CHECK("k_churn");
+    if ((rc = eval_F(p, w, p->b_eff + (size_t)p->n_levels * p->hid, st))) return rc;
+    if (heun) {
+        StepCommon c;
+        memset(&c, 0, sizeof c);
+        c.x_hat = w.x_hat; c.d_cur = w.d_cur; c.F = w.F; c.u = w.u; c.n_cells = cells; c.n_rows = n;
+        c.D = D; c.ldF = p->N5; c.ldu = p->K1; c.u_bf16 = bf;
+        hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, k0.c_skip, k0.c_out, th, h, k1.c_in);
+        DP_LAUNCH_CHECK("k_step_mid");
+        if ((rc = eval_F(p, w, p->b_eff + (size_t)(p->n_levels + 1) * p->hid, st))) return rc;
+        hipLaunchKernelGGL(k_heun_out, dim3(g), dim3(256), 0, st, (const float*)w.x_hat, (const float*)w.d_cur, (const float*)w.F, p->N5, x_next, cells, D,
+                           k1.c_skip, k1.c_out, t_next, h, 1);
+    } else {
+        hipLaunchKernelGGL(k_heun_out, dim3(g), dim3(256), 0, st, (const float*)w.x_hat, (const float*)nullptr, (const float*)w.F, p->N5, x_next, cells, D,
+                           k0.c_skip, k0.c_out, th, h, 0);
+    }
+    DP_LAUNCH_CHECK("k_heun_out");
+    return DP_OK;
+}
+
+int dp_plan_schedule(const dp_plan* p, float* t_out) {
+    if (!p || !t_out) return fail(DP_EINVAL, "NULL argument");
+    memcpy(t_out, p->t.data(), p->t.size() * sizeof(float));
+    return DP_OK;
+}
+
+int dp_plan_levels(const dp_plan* p, float* sigma_out) {
+    if (!p || !sigma_out) return fail(DP_EINVAL, "NULL argument");
+    for (int e = 0; e < p->n_levels; ++e) sigma_out[e] = p->lv[e].sigma;
+    return DP_OK;
+}
+
+int dp_plan_embedding(const dp_plan* p, float* emb_out) {
+    int rc = check_plan(p, true);
+    if (rc) return rc;
+    if (!emb_out) return fail(DP_EINVAL, "NULL argument");
+    DP_HIP(hipDeviceSynchronize());
+    DP_HIP(hipMemcpy(emb_out, p->b_eff, (size_t)p->n_levels * p->hid * 4, hipMemcpyDeviceToHost));
+    return DP_OK;
+}
+
+int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* out, int64_t M, int N, int K, int act, int out_f32,
+              void* stream) {
+    if (!A || !W || !bias || !out) return fail(DP_EINVAL, "NULL argument");
+    if (dtype == DP_DTYPE_F32) out_f32 = 1;
+    return gemm(dtype, A, W, bias, out, N, M, N, K, act ? 1 : 0, out_f32 ? 1 : 0, (hipStream_t)stream);
+}
+
+int dp_noise_field(float* out, int64_t n_rows, int d_in, uint64_t seed, uint64_t row_offset, int trial, uint32_t block, int comp,
+                   void* stream) {
+    if (!out || n_rows <= 0 || d_in <= 0 || d_in > 65535 || trial < 0 || trial > 65535 || comp < 0 || comp > 3)
+        return fail(DP_EINVAL, "dp_noise_field: bad argument");
+    hipLaunchKernelGGL(k_noise_field, dim3(grid_for(n_rows * d_in)), dim3(256), 0, (hipStream_t)stream, out, n_rows, d_in, seed, row_offset, trial,
+                       block, comp);
+    DP_LAUNCH_CHECK("k_noise_field");
+    return DP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// Fused elementwise kernels of the masked EDM sampler: one launch per denoiser evaluation.
+//
+// Every kernel works on chains: chain m = trial_local * n_rows + row carries one row of the table through one
+// trial.  State per chain (float32 [M, D]): x_hat (the churned state fed to the first evaluation of an inner
+// iteration) and d_cur (the Euler slope).  x_t itself is never stored: the kernel that finishes inner
+// iteration `it` immediately applies the churn of iteration it+1 and writes x_hat and the network input
+// u = c_in * x_hat for the next evaluation.  Reference code being restated (diffusion_utils.py):
+//   init : x_t = randn * t0 (:25,:35); churn x_hat = x_t + sqrt(t_hat^2 - t_cur^2) * eps (:96)
+//   mid  : D = c_skip x_hat + c_out F (model.py:164); d_cur = (x_hat - D)/t_hat (:100); x_e = x_hat + (t_next - t_hat) d_cur (:101)
+//   end  : d' = (x_e - D(x_e))/t_next (:106); Heun (:107); x_known = x + randn * t_next (:45,:47);
+//          blend x_known (1-mask) + x_unknown mask (:50); re-noise + randn * sqrt(t_cur^2 - t_next^2) iff j < R-1 (:52-57);
+//          then the churn (:96) of the next inner iteration
+//   final: Euler-only last level (t_next = 0, :58-66) + the caller's blend and trial sum (main.py:182-188)
+// Arithmetic is float32 in the reference's operation order; contraction into fma is disabled so the float32
+// path rounds like the reference's separate torch ops.
+#pragma once
+#include "dp_philox.h"
+
+namespace dp {
+
+struct StepCommon {
+    float* x_hat;          // [M, D]
+    float* d_cur;          // [M, D]
+    const float* F;        // [Mp, ldF] raw network output of the evaluation that just ran
+    void* u;               // [Mp, ldu] network input for the next evaluation (bf16 or f32)
+    const float* x_obs;    // [n_rows, D]
+    const uint8_t* mask;   // [n_rows, D], 1 = missing
+    const float* noise;    // NULL or [T, n_draws, n_rows, D]
+    float* trace;          // NULL or [n_iter, T, n_rows, D]
+    int64_t n_cells;       // M * D
+    int64_t n_rows;
+    int64_t draw_stride;   // n_rows * D
+    int64_t trial_stride;  // n_draws * n_rows * D
+    uint64_t seed, row_offset;
+    int D, ldF, ldu, u_bf16, trial_offset, num_trials;
+};
+
+__device__ __forceinline__ void store_u(const StepCommon& c, int64_t m, int col, float v) {
+    if (c.u_bf16) ((bf16_t*)c.u)[m * c.ldu + col] = f2bf(v);
+    else ((float*)c.u)[m * c.ldu + col] = v;
+}
+
+struct Cell { int64_t m, row; int col, tl; };
+__device__ __forceinline__ Cell cell_of(const StepCommon& c, int64_t e) {
+    Cell k;
+    k.m = e / c.D;
+    k.col = (int)(e - k.m * c.D);
+    k.tl = (int)(k.m / c.n_rows);
+    k.row = k.m - (int64_t)k.tl * c.n_rows;
+    return k;
+}
+// reference draw k of trial tl at (row, col) in injected-noise mode
+__device__ __forceinline__ float draw(const StepCommon& c, const Cell& k, int64_t idx) {
+    return c.noise[(int64_t)k.tl * c.trial_stride + idx * c.draw_stride + k.row * c.D + k.col];
+}
+
+#pragma clang fp contract(off)
+
+// x_t = z0 * t0, then the churn of inner iteration 0.
+__global__ __launch_bounds__(256) void k_step_init(StepCommon c, float t0, float churn0, float c_in0) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < c.n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const Cell k = cell_of(c, e);
+        float z0, zc;
+        if (c.noise) {
+            z0 = draw(c, k, 0);
+            zc = draw(c, k, 3);                      // iteration 0: draws 1 n_curr, 2 n_prev, 3 churn, 4 n
+        } else {
+            float a, b;
+            philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), DP_PHILOX_INIT_BLOCK, z0, a, zc, b);
+        }
+        const float x_t = z0 * t0;
+        const float xh = x_t + churn0 * zc;
+        c.x_hat[e] = xh;
+        store_u(c, k.m, k.col, c_in0 * xh);
+    }
+}
+
+// After the first evaluation of an inner iteration at a Heun level.
+__global__ __launch_bounds__(256) void k_step_mid(StepCommon c, float c_skip, float c_out, float t_hat, float h, float c_in_next) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < c.n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / c.D;
+        const int col = (int)(e - m * c.D);
+        const float xh = c.x_hat[e];
+        const float Fx = c.F[m * c.ldF + col];
+        const float den = c_skip * xh + c_out * Fx;
+        const float d = (xh - den) / t_hat;
+        const float xe = xh + h * d;
+        c.d_cur[e] = d;
+        store_u(c, m, col, c_in_next * xe);
+    }
+}
+
+// After the second evaluation: Heun, observed-value blend, re-noise, next churn.
+//   it = global inner-iteration index; renoise > 0 iff j < R-1; churn_next/c_in_next belong to iteration it+1.
+__global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_skip, float c_out, float t_next, float h,
+                                                  float renoise, int add_renoise, float churn_next, float c_in_next) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < c.n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const Cell k = cell_of(c, e);
+        float z_prev, z_re, z_churn;
+        if (c.noise) {
+            const int64_t base = 1 + 4 * (int64_t)it;
+            z_prev = draw(c, k, base + 1);
+            z_re = add_renoise ? draw(c, k, base + 3) : 0.f;
+            z_churn = draw(c, k, base + 4 + 2);      // churn draw of iteration it+1
+        } else {
+            float unused;
+            philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), (uint32_t)it, z_prev, z_re, z_churn, unused);
+        }
+        const float xh = c.x_hat[e];
+        const float d = c.d_cur[e];
+        const float xe = xh + h * d;
+        const float Fx = c.F[k.m * c.ldF + k.col];
+        const float den = c_skip * xe + c_out * Fx;
+        const float dp = (xe - den) / t_next;
+        const float xn = xh + h * (0.5f * d + 0.5f * dp);
+        const int64_t oc = k.row * c.D + k.col;
+        const float mk = (float)c.mask[oc];
+        const float xk = c.x_obs[oc] + z_prev * t_next;
+        float x_t = xk * (1.0f - mk) + xn * mk;
+        if (add_renoise) x_t = x_t + z_re * renoise;
+        if (c.trace) c.trace[(int64_t)it * c.n_cells + e] = x_t;
+        const float xh2 = x_t + churn_next * z_churn;
+        c.x_hat[e] = xh2;
+        store_u(c, k.m, k.col, c_in_next * xh2);
+    }
+}
+
+// Last level (t_next = 0): Euler step = the denoised sample; blend; caller's blend; sum over this call's trials.
+// One thread per (row, col); trials are summed in order, so the result is deterministic.
+__global__ __launch_bounds__(256) void k_step_final(StepCommon c, int it, float c_skip, float c_out, float t_hat, float h,
+                                                    float* __restrict__ out, int accumulate) {
+    const int64_t per_trial = c.n_rows * c.D;
+    for (int64_t oc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; oc < per_trial; oc += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = oc / c.D;
+        const int col = (int)(oc - row * c.D);
+        const float mk = (float)c.mask[oc];
+        const float xo = c.x_obs[oc];
+        float sum = accumulate ? out[oc] : 0.f;
+        for (int tl = 0; tl < c.num_trials; ++tl) {
+            const int64_t e = (int64_t)tl * per_trial + oc;
+            const int64_t m = (int64_t)tl * c.n_rows + row;
+            const float xh = c.x_hat[e];
+            const float Fx = c.F[m * c.ldF + col];
+            const float den = c_skip * xh + c_out * Fx;
+            const float d = (xh - den) / t_hat;
+            const float xe = xh + h * d;
+            // x_known = x + randn * 0 = x (:60-62); blend (:65)
+            const float x_t = xo * (1.0f - mk) + xe * mk;
+            if (c.trace) c.trace[(int64_t)it * c.n_cells + e] = x_t;
+            sum = sum + (x_t * mk + xo * (1.0f - mk));       // main.py:183
+        }
+        out[oc] = sum;
+    }
+}
+
+// --- stand-alone pieces used by dp_denoise / dp_sample_step (the reference's net(x, sigma) and sample_step) ---
+
+// u = c_in * x  (model.py:160)
+__global__ __launch_bounds__(256) void k_scale_in(const float* __restrict__ x, void* u, int ldu, int u_bf16, int64_t n_cells, int D, float c_in) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / D;
+        const int col = (int)(e - m * D);
+        const float v = c_in * x[e];
+        if (u_bf16) ((bf16_t*)u)[m * ldu + col] = f2bf(v);
+        else ((float*)u)[m * ldu + col] = v;
+    }
+}
+
+// D = c_skip x + c_out F (model.py:164); optionally also copy F out densely.
+__global__ __launch_bounds__(256) void k_precond_out(const float* __restrict__ x, const float* __restrict__ F, int ldF, float* D_out,
+                                                     float* F_out, int64_t n_cells, int D, float c_skip, float c_out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / D;
+        const int col = (int)(e - m * D);
+        const float Fx = F[m * ldF + col];
+        if (F_out) F_out[e] = Fx;
+        if (D_out) D_out[e] = c_skip * x[e] + c_out * Fx;
+    }
+}
+
+// churn for dp_sample_step: x_hat = x_cur + churn * eps
+__global__ __launch_bounds__(256) void k_churn(const float* __restrict__ x_cur, const float* __restrict__ eps, float* x_hat, void* u, int ldu,
+                                               int u_bf16, int64_t n_cells, int D, float churn, float c_in, uint64_t seed,
+                                               uint64_t row_offset, uint32_t block) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / D;
+        const int col = (int)(e - m * D);
+        float z;
+        if (eps) z = eps[e];
+        else { float a, b, cc; philox_normal4(seed, row_offset + m, trial_col(0, col), block, a, b, z, cc); }
+        const float xh = x_cur[e] + churn * z;
+        x_hat[e] = xh;
+        const float v = c_in * xh;
+        if (u_bf16) ((bf16_t*)u)[m * ldu + col] = f2bf(v);
+        else ((float*)u)[m * ldu + col] = v;
+    }
+}
+
+// second half of sample_step at a Heun level / result of the Euler-only last level
+__global__ __launch_bounds__(256) void k_heun_out(const float* __restrict__ x_hat, const float* __restrict__ d_cur, const float* __restrict__ F,
+                                                  int ldF, float* x_next, int64_t n_cells, int D, float c_skip, float c_out, float t_div,
+                                                  float h, int heun) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / D;
+        const int col = (int)(e - m * D);
+        const float xh = x_hat[e];
+        const float Fx = F[m * ldF + col];
+        if (heun) {
+            const float d = d_cur[e];
+            const float xe = xh + h * d;
+            const float den = c_skip * xe + c_out * Fx;
+            const float dp = (xe - den) / t_div;
+            x_next[e] = xh + h * (0.5f * d + 0.5f * dp);
+        } else {
+            const float den = c_skip * xh + c_out * Fx;
+            const float d = (xh - den) / t_div;
+            x_next[e] = xh + h * d;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_noise_field(float* out, int64_t n_rows, int D, uint64_t seed, uint64_t row_offset, int trial,
+                                                     uint32_t block, int comp) {
+    const int64_t n = n_rows * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / D;
+        const int col = (int)(e - row * D);
+        float z[4];
+        philox_normal4(seed, row_offset + row, trial_col(trial, col), block, z[0], z[1], z[2], z[3]);
+        out[e] = comp == 0 ? z[0] : comp == 1 ? z[1] : comp == 2 ? z[2] : z[3];
+    }
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace dp

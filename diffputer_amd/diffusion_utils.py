@@ -1,0 +1,104 @@
+"""Drop-in for the reference's `diffusion_utils` sampler API (diffusion_utils.py:13-109).
+
+Same names, argument order and meaning as the reference, so `main.py:14`
+(`from diffusion_utils import sample_step, impute_mask`) and its call sites (:180, :231) work
+unchanged; the work is done by libdiffputer_hip.so through `SamplerPlan`.  Extra keyword-only
+arguments (noise=, seed=, dtype=, trace=) are additions; with none given the behaviour is the
+reference's: fresh Gaussian noise on every call.
+
+Not here (stays PyTorch): the training losses (EDMLoss is in model.py; VPLoss /
+VELoss are dead code in the reference).
+"""
+from __future__ import annotations
+
+import itertools
+import weakref
+
+import numpy as np
+import torch
+
+from .sampler import SamplerPlan
+
+# diffusion_utils.py:15-21 -- fixed inside the native sampler; exported for callers that read them
+SIGMA_MIN = 0.002
+SIGMA_MAX = 80
+rho = 7
+S_churn = 1
+S_min = 0
+S_max = float("inf")
+S_noise = 1
+N_RESAMPLE = 20            # the local `N = 20` of diffusion_utils.py:37
+
+_default_dtype = "bf16"
+_seed_counter = itertools.count(int(np.random.SeedSequence().generate_state(1)[0]))
+_plans: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def set_default_dtype(dtype: str):
+    """'bf16' (default: bf16 MFMA GEMMs, fp32 accumulate and fp32 sampler state) or 'f32'."""
+    global _default_dtype
+    if dtype not in ("bf16", "f32"):
+        raise ValueError("dtype must be 'bf16' or 'f32'")
+    _default_dtype = dtype
+
+
+def _check_net(net):
+    # the reference reads these at diffusion_utils.py:27-28,32; the native schedule hard-codes their defaults
+    if max(SIGMA_MIN, getattr(net, "sigma_min", 0)) != SIGMA_MIN or min(SIGMA_MAX, getattr(net, "sigma_max", float("inf"))) != SIGMA_MAX:
+        raise NotImplementedError("net.sigma_min/sigma_max other than the reference defaults (0, inf) are not supported")
+    if getattr(net, "sigma_data", 0.5) != 0.5:
+        raise NotImplementedError("sigma_data != 0.5 is not supported")
+
+
+def plan_for(net, num_steps: int, device, dtype: str | None = None, n_resample: int = N_RESAMPLE) -> SamplerPlan:
+    """Plan cache keyed on the net object and on the identity/version of its weights: the reference
+    rebuilds the model and reloads model.pt for every trial (main.py:170-173); here the packed
+    weights are reused until a parameter changes."""
+    _check_net(net)
+    dtype = dtype or _default_dtype
+    dev = torch.device(device)
+    params = list(net.parameters())
+    sig = (num_steps, n_resample, dtype, str(dev), tuple((p.data_ptr(), p._version) for p in params))
+    cached = _plans.get(net)
+    if cached is not None and cached[0] == sig:
+        return cached[1]
+    plan = SamplerPlan(net, num_steps=num_steps, n_resample=n_resample, dtype=dtype, device=dev)
+    _plans[net] = (sig, plan)
+    return plan
+
+
+def impute_mask(net, x, mask, num_samples, dim, num_steps=50, device="cuda:0", *, noise=None, seed=None, dtype=None,
+                trace=False, n_resample=N_RESAMPLE):
+    """Masked reverse diffusion with RePaint resampling (diffusion_utils.py:23-68).
+
+    net: the Precond module (`model.denoise_fn_D`); x [num_samples, dim] observed values (zero at
+    missing cells); mask bool, True = missing.  Returns x_0 [num_samples, dim] float32 on `device`.
+    noise: optional [n_draws, N, D] replay of the reference's Gaussian draws (parity tests).
+    """
+    if tuple(x.shape) != (num_samples, dim):
+        raise ValueError(f"x has shape {tuple(x.shape)} but num_samples, dim = {num_samples}, {dim}")
+    plan = plan_for(net, num_steps, device, dtype, n_resample)
+    if seed is None:
+        seed = next(_seed_counter)
+    out, tr = plan.impute_sum(x, mask, 1, seed=seed, noise=noise, trace=trace)
+    return (out, tr[:, 0]) if trace else out
+
+
+def sample_step(net, num_steps, i, t_cur, t_next, x_next, *, eps=None, seed=None, dtype=None):
+    """One stochastic EDM step: churn, Euler, Heun iff i < num_steps-1 (diffusion_utils.py:90-109)."""
+    plan = plan_for(net, num_steps, x_next.device, dtype)
+    if seed is None:
+        seed = next(_seed_counter)
+    return plan.sample_step(int(i), float(t_cur), float(t_next), x_next, eps, seed=seed)
+
+
+def sample(net, num_samples, dim, num_steps=50, device="cuda:0", *, seed=None, dtype=None):
+    """Unconditional EDM sampler (diffusion_utils.py:70-88; not called by main.py): the same kernels
+    with every cell missing and no resampling."""
+    plan = plan_for(net, num_steps, device, dtype, n_resample=1)
+    if seed is None:
+        seed = next(_seed_counter)
+    x = torch.zeros((num_samples, dim), dtype=torch.float32, device=device)
+    m = torch.ones((num_samples, dim), dtype=torch.uint8, device=device)
+    out, _ = plan.impute_sum(x, m, 1, seed=seed)
+    return out

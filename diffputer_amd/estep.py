@@ -1,0 +1,99 @@
+"""The E-step driver: trial loop, final blend, trial mean -- and the row sharding across GPUs.
+
+Counterpart of main.py:156-193 (in-sample) and :208-246 (out-of-sample).  Differences that do not
+change results: the model is not rebuilt / model.pt not re-read per trial (main.py:170-173 is a
+no-op semantically); trials are folded into the batch (chains = rows x trials) and summed on the
+device in trial order instead of `torch.stack(...).mean(0)` (main.py:188).
+
+Multi-GPU: rows are independent Markov chains given the weights, so each rank takes
+a contiguous row shard and all trials of it; the only collective is one all-gather of the
+trial-mean shards at the end (RCCL over xGMI when the process group is `nccl`).  Noise is
+counter-based (global row, global trial), so the result is the same for any number of ranks.
+"""
+from __future__ import annotations
+
+import torch
+
+from .diffusion_utils import N_RESAMPLE, plan_for
+from .sampler import SamplerPlan
+
+DEFAULT_MAX_CHAINS = 1 << 16     # chains per dp_impute call: bounds the workspace (about 20 KB/chain in bf16)
+
+
+def shard_bounds(n_rows: int, world_size: int, rank: int):
+    """Contiguous, balanced row shard [r0, r1) of rank `rank` (first n % W ranks get one extra row)."""
+    base, extra = divmod(n_rows, world_size)
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def plan_calls(n_rows: int, num_trials: int, max_chains: int):
+    """Split rows x trials into dp_impute calls of at most `max_chains` chains.
+    Yields (r0, r1, t0, t1).  Small tables batch several trials per call; large ones chunk rows."""
+    if n_rows >= max_chains:
+        for r0 in range(0, n_rows, max_chains):
+            for t in range(num_trials):
+                yield r0, min(n_rows, r0 + max_chains), t, t + 1
+    else:
+        per = max(1, max_chains // n_rows)
+        for t0 in range(0, num_trials, per):
+            yield 0, n_rows, t0, min(num_trials, t0 + per)
+
+
+def impute_trials(plan: SamplerPlan, X, mask, num_trials: int, *, seed: int = 0, row_offset: int = 0,
+                  max_chains: int = DEFAULT_MAX_CHAINS, prefilled: bool = False) -> torch.Tensor:
+    """Mean over `num_trials` trials of rec*mask + x_obs*(1-mask) for the rows given (main.py:160-188).
+    X [n, D] float32 in the sampler's scale ((x-mean)/std/2, main.py:58); mask True = missing."""
+    dev = plan.device
+    X = torch.as_tensor(X).to(dev, torch.float32)
+    m = torch.as_tensor(mask).to(dev)
+    x_obs = X if prefilled else ((1.0 - m.to(torch.float32)) * X)            # main.py:164
+    m8 = m.to(torch.uint8).contiguous()
+    out = torch.zeros_like(x_obs)
+    n = x_obs.shape[0]
+    if n == 0:
+        return out
+    for r0, r1, t0, t1 in plan_calls(n, num_trials, max_chains):
+        plan.impute_sum(x_obs[r0:r1], m8[r0:r1], t1 - t0, seed=seed, row_offset=row_offset + r0, trial_offset=t0,
+                        out=out[r0:r1], accumulate=t0 > 0)
+    return out / num_trials                                                 # the .mean(0) of main.py:188
+
+
+def e_step(net, X, mask, num_trials: int = 20, num_steps: int = 50, device="cuda:0", *, seed: int = 0, dtype=None,
+           n_resample: int = N_RESAMPLE, max_chains: int = DEFAULT_MAX_CHAINS, group=None, gather: bool = True) -> torch.Tensor:
+    """Full E-step for one table: returns the trial-mean imputation [N, D] in the sampler's scale
+    (the caller multiplies by 2 and saves iter_{k+1}.npy, main.py:190-193).
+
+    With torch.distributed initialised, every rank passes the same full X/mask, samples its own
+    row shard and receives the gathered result (gather=False returns only the local shard)."""
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    n = X.shape[0]
+    r0, r1 = shard_bounds(n, world, rank)
+    plan = plan_for(net, num_steps, device, dtype, n_resample)
+    local = impute_trials(plan, X[r0:r1], mask[r0:r1], num_trials, seed=seed, row_offset=r0, max_chains=max_chains)
+    if world == 1 or not gather:
+        return local
+    return gather_rows(local, n, group)
+
+
+def gather_rows(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
+    """All-gather of contiguous row shards (shard_bounds layout) into the full [n_rows, D] table on every rank.
+    Shards differ by at most one row, so they are padded to the largest and gathered in one collective."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    d = local.shape[1]
+    biggest = -(-n_rows // world)
+    pad = torch.zeros((biggest, d), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    buf = torch.empty((world * biggest, d), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(n_rows, world, r)
+        parts.append(buf[r * biggest: r * biggest + (b - a)])
+    return torch.cat(parts, dim=0)

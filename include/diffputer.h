@@ -1,0 +1,153 @@
+/*
+ * diffputer.h -- C ABI of libdiffputer_hip.so: DiffPuter's E-step imputation sampler on MI355X (gfx950).
+ *
+ * The reference (hengruizhang98/DiffPuter) is pure Python and has no FFI layer; the seam this library
+ * sits behind is the Python import `from diffusion_utils import sample_step, impute_mask`
+ * (main.py:14) and the two call sites main.py:180 and main.py:231.  Each entry point below names the
+ * reference code it replaces (paths relative to the reference root).  The Python host side
+ * (diffputer_amd/diffusion_utils.py) binds these with ctypes and keeps the reference's signatures;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every pointer named x, mask, out, noise, trace, workspace, w[], b[] is a DEVICE pointer owned by the
+ *     caller (PyTorch).  The library borrows it for the duration of the call.  No torch types cross here.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  All work is enqueued on it; no entry
+ *     point synchronises the device except dp_plan_set_weights (once per checkpoint) and the test getters.
+ *   - Return value 0 = DP_OK, negative = error; dp_last_error() gives the message (thread-local).
+ *   - Tables are row-major float32 [rows, d_in]; masks are uint8 [rows, d_in] with 1 = MISSING
+ *     (generate_mask.py:513-514, main.py:85).
+ *   - A plan is bound to the device that was current at dp_plan_create and is not thread-safe.
+ */
+#ifndef DIFFPUTER_H
+#define DIFFPUTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DP_OK            0
+#define DP_EINVAL       -1   /* bad argument (shape, alignment, null pointer, unsupported size) */
+#define DP_EHIP         -2   /* a HIP runtime call failed; message carries hipGetErrorString */
+#define DP_ESTATE       -3   /* call order violated (e.g. impute before set_weights) */
+#define DP_EWORKSPACE   -4   /* workspace too small for the requested number of chains */
+
+#define DP_DTYPE_F32     0   /* GEMM operands float32, v_mfma_f32_32x32x2_f32 (exact f32 fma chain) */
+#define DP_DTYPE_BF16    1   /* GEMM operands bfloat16, fp32 accumulate, v_mfma_f32_16x16x32_bf16 */
+
+/* dp_impute flags */
+#define DP_ACCUMULATE    1   /* out += sum over this call's trials (default: out = sum) */
+
+typedef struct dp_plan dp_plan;
+
+/* Library ABI version (this header: 1). */
+int dp_version(void);
+
+/* Message of the last error raised on the calling thread ("" if none). */
+const char* dp_last_error(void);
+
+/*
+ * Create a sampler plan for a denoiser of input width d_in and hidden width hid.
+ * Replaces: the schedule/constant set-up at the top of impute_mask (diffusion_utils.py:24-37, constants
+ * :15-21, N = 20 at :37) and the shape part of MLPDiffusion.__init__ (model.py:97-119).
+ *   num_steps   S  (main.py:28 --num_steps, default 50), >= 2
+ *   n_resample  R  (the local `N = 20` of diffusion_utils.py:37; 10 in baselines/Missdiff_SDE), >= 1
+ *   dtype       DP_DTYPE_F32 or DP_DTYPE_BF16
+ * Constraints: hid % 64 == 0, 1 <= d_in <= 4096.
+ */
+int dp_plan_create(dp_plan** out, int d_in, int hid, int num_steps, int n_resample, int dtype);
+
+/*
+ * Load a checkpoint's 14 tensors (device pointers, float32, torch.nn.Linear layout [out, in] row-major).
+ * Replaces: `model.load_state_dict(torch.load(.../model.pt))` per trial (main.py:170-173) and, for the
+ * 2*S-1 noise levels a run visits, the whole timestep-embedding branch of MLPDiffusion.forward
+ * (PositionalEmbedding model.py:24-30, sin/cos swap :123, time_embed :124) folded with proj.bias into one
+ * bias row per level.
+ * Order of w[]/b[]: 0 proj, 1 mlp.0, 2 mlp.2, 3 mlp.4, 4 mlp.6, 5 time_embed.0, 6 time_embed.2.
+ * The plan keeps its own packed copies; the caller's tensors may be freed after the call returns
+ * (the call synchronises `stream`).
+ */
+int dp_plan_set_weights(dp_plan* plan, const float* const w[7], const float* const b[7], void* stream);
+
+void dp_plan_destroy(dp_plan* plan);
+
+/* Bytes of device workspace dp_impute / dp_denoise / dp_sample_step need for `n_chains` chains
+ * (a chain = one row x one trial).  0 on error. */
+size_t dp_workspace_bytes(const dp_plan* plan, int64_t n_chains);
+
+/*
+ * The E-step sampler for `num_trials` trials of `n_rows` rows (n_rows * num_trials chains in one batch).
+ * Replaces: impute_mask (diffusion_utils.py:23-68) including every sample_step (:90-109) and
+ * Precond/MLPDiffusion forward (model.py:121-128,148-165) it makes, plus the caller's per-trial blend and
+ * trial sum (main.py:182-188: rec*mask + x*(1-mask), stack().mean(0) -- the mean's division by T is left
+ * to the caller).
+ *   x_obs      [n_rows, d_in]  observed values, the `x` of impute_mask (zero at missing cells, main.py:164)
+ *   mask       [n_rows, d_in]  uint8, 1 = missing
+ *   out        [n_rows, d_in]  sum over the trials of rec*mask + x_obs*(1-mask)
+ *   seed, row_offset, trial_offset
+ *              counter-based Philox4x32-10 noise keyed by (seed; global row = row_offset + r, global trial =
+ *              trial_offset + t, column, draw block): results do not depend on how rows/trials are sharded.
+ *   noise      NULL, or [num_trials, n_draws, n_rows, d_in] float32: the reference's Gaussian draws in
+ *              program order (n_draws = 1 + 4*R*(S-1) + 3; draw 0 = torch.randn :25, then per inner iteration
+ *              n_curr :44 (unused), n_prev :45, churn eps :96, n :52).  Used instead of Philox: parity mode.
+ *   trace      NULL, or [n_iter, num_trials, n_rows, d_in] float32 receiving x_t after every inner iteration
+ *              (n_iter = R*(S-1) + 1).
+ *   flags      DP_ACCUMULATE or 0
+ */
+int dp_impute(dp_plan* plan, const float* x_obs, const uint8_t* mask, float* out,
+              int64_t n_rows, int num_trials, uint64_t seed, uint64_t row_offset, int trial_offset,
+              const float* noise, float* trace, int flags,
+              void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * One denoiser evaluation D(x, sigma) for a batch-wide scalar sigma.
+ * Replaces: Precond.forward(x, sigma) with 0-dim sigma (model.py:148-165), i.e. the `net(x_hat, t_hat)`
+ * calls at diffusion_utils.py:99,105.
+ *   x [n, d_in] -> D_out [n, d_in] (may be NULL), F_out [n, d_in] = raw network output F_x (may be NULL)
+ */
+int dp_denoise(dp_plan* plan, const float* x, float sigma, float* D_out, float* F_out, int64_t n,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * One stochastic EDM step.  Replaces: sample_step(net, num_steps, i, t_cur, t_next, x_next)
+ * (diffusion_utils.py:90-109): churn to t_hat = 1.02 t_cur (gamma = min(S_churn/S, sqrt2-1)), Euler step,
+ * Heun correction iff i < num_steps-1.
+ *   eps  [n, d_in] the churn draw of :96, or NULL to use Philox (seed, row_offset, draw block `block`)
+ */
+int dp_sample_step(dp_plan* plan, int i, float t_cur, float t_next, const float* x_cur, const float* eps,
+                   float* x_next, int64_t n, uint64_t seed, uint64_t row_offset, uint32_t block,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Test/inspection getters (host output pointers; they synchronise the stream they use).
+ *   dp_plan_schedule:  t_out[S+1] = sigma schedule with trailing 0 (diffusion_utils.py:24-32)
+ *   dp_plan_levels:    sigma_out[2S-1] = the noise levels a run evaluates, [2i] = t_hat_i, [2i+1] = t_{i+1}
+ *   dp_plan_embedding: emb_out[(2S-1) * hid] = proj.bias + time_embed(posemb(ln(sigma)/4)) per level
+ */
+int dp_plan_schedule(const dp_plan* plan, float* t_out);
+int dp_plan_levels(const dp_plan* plan, float* sigma_out);
+int dp_plan_embedding(const dp_plan* plan, float* emb_out);
+
+/*
+ * Single-kernel test entry: out[M, N] = act(A[M, K] @ W[N, K]^T + bias[N]) with the plan-independent GEMM
+ * kernels (model.py:102-111 are five such layers).  dtype as above: for DP_DTYPE_BF16, A and W are bf16
+ * (uint16 bit patterns) and out is bf16 unless out_f32 != 0; for DP_DTYPE_F32 everything is float32.
+ * Constraints: M % 256 == 0, N % 64 == 0, K % 64 == 0.  act: 0 = none, 1 = SiLU.
+ */
+int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* out,
+              int64_t M, int N, int K, int act, int out_f32, void* stream);
+
+/*
+ * Fill out[n_rows, d_in] with the Philox Gaussian field of draw block `block`, component `comp` (0..3), for
+ * global rows row_offset.. and global trial `trial` (the noise dp_impute uses when noise == NULL).
+ * No counterpart in the reference (it uses torch's global RNG, unseeded).
+ */
+int dp_noise_field(float* out, int64_t n_rows, int d_in, uint64_t seed, uint64_t row_offset, int trial,
+                   uint32_t block, int comp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFPUTER_H */

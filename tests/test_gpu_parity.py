@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (BASELINE.json north_star): float32 path -- every inner-iteration x_t within 1e-3
+relative of the oracle, |d| <= 1e-3 * max(|ref|, 1e-2 * sigma_level); bf16 path -- looser, stated
+per test from SURVEY.md §0's measurement (bf16-rounded GEMM operands: final output max-abs 1.7e-3
+at H=1024 on a trained net; random nets with gain 2 are less contractive, so the bound here is
+5e-2 abs on trajectories and 2e-2 rel on single evaluations).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_noise, load_golden
+from diffputer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _plan(sd, S, R, dtype):
+    from diffputer_amd.sampler import SamplerPlan
+    return SamplerPlan({k: torch.from_numpy(v) for k, v in sd.items()}, num_steps=S, n_resample=R, dtype=dtype, device=DEV)
+
+
+def _sd(g):
+    return synth.make_weights(int(g["d_in"]), int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+
+
+def rel_check(got, ref, floor, rtol=1e-3, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    lim = rtol * np.maximum(np.abs(ref), floor)
+    err = np.abs(got - ref)
+    assert np.all(np.isfinite(got)), what
+    assert np.all(err <= lim), f"{what}: max err {err.max():.3e}, worst ratio {(err / lim).max():.2f}"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM kernels
+@pytest.mark.parametrize("M,N,K", [(256, 64, 64), (512, 128, 192), (256, 256, 64), (768, 512, 256), (512, 2048, 1024)])
+@pytest.mark.parametrize("act", [False, True])
+def test_linear_bf16(M, N, K, act):
+    from diffputer_amd.sampler import linear
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    W += torch.arange(N).reshape(N, 1) * 1e-3          # asymmetric: a transposed C write cannot pass
+    b = torch.randn(N, generator=g)
+    Ab, Wb = A.bfloat16(), W.bfloat16()
+    ref = Ab.float() @ Wb.float().T + b
+    if act:
+        ref = torch.nn.functional.silu(ref)
+    for out_f32 in (False, True):
+        got = linear(Ab.to(DEV), Wb.to(DEV), b.to(DEV), act=act, out_f32=out_f32).float().cpu()
+        tol = 2e-3 if out_f32 else 1e-2                  # fp32 accumulate; bf16 output rounding 2^-9
+        assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 64, 64), (512, 192, 128), (256, 2048, 1024)])
+@pytest.mark.parametrize("act", [False, True])
+def test_linear_f32(M, N, K, act):
+    from diffputer_amd.sampler import linear
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5 + torch.arange(N).reshape(N, 1) * 1e-3
+    b = torch.randn(N, generator=g)
+    ref = (A.double() @ W.double().T + b.double())
+    if act:
+        ref = torch.nn.functional.silu(ref)
+    got = linear(A.to(DEV), W.to(DEV), b.to(DEV), act=act).cpu().double()
+    assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5), (got - ref).abs().max()
+
+
+# ------------------------------------------------------------------------------------------------ plan tables
+def test_schedule_and_levels():
+    g = load_golden("schedule")
+    for S in (5, 10, 50):
+        p = _plan(synth.make_weights(9, 64, 1), S, 20, "f32")
+        t = p.schedule()
+        ref = g[f"t_S{S}"]
+        assert np.all(np.abs(t - ref) <= 2 * np.spacing(ref)), t - ref
+        lv = p.levels()
+        th = (t[:-1] + np.float32(min(1.0 / S, np.sqrt(2) - 1)) * t[:-1]).astype(np.float32)
+        assert np.allclose(lv[0::2], th, rtol=1e-6) and np.allclose(lv[1::2], t[1:-1], rtol=1e-6)
+        p.close()
+
+
+@pytest.mark.parametrize("hid", [64, 1024])
+def test_embedding_table(hid):
+    g = load_golden(f"embedding_H{hid}")
+    sd = synth.make_weights(9, hid, int(g["wseed"]), float(g["gain"]))
+    p = _plan(sd, 50, 20, "f32")
+    assert np.allclose(p.levels(), g["sigma"], rtol=1e-6)
+    want = g["emb"] + sd[synth.CKPT_PREFIX + "proj.bias"][None, :]
+    got = p.embedding()
+    assert np.abs(got - want).max() <= 2e-5, np.abs(got - want).max()
+    p.close()
+
+
+# ------------------------------------------------------------------------------------------------ single evaluation
+@pytest.mark.parametrize("d_in", [9, 64, 256])
+@pytest.mark.parametrize("dtype,rtol", [("f32", 1e-4), ("bf16", 2e-2)])
+def test_denoise_golden(d_in, dtype, rtol):
+    g = load_golden(f"denoiser_D{d_in}_H1024")
+    p = _plan(_sd(g), 50, 20, dtype)
+    for k, s in enumerate(g["sigma"]):
+        D, F = p.denoise(g["x"][k], float(s), want_F=True)
+        F = F.cpu().numpy()
+        D = D.cpu().numpy()
+        fscale = float(np.abs(g["F"][k]).max())
+        assert np.abs(F - g["F"][k]).max() <= rtol * fscale, (dtype, s, np.abs(F - g["F"][k]).max(), fscale)
+        dscale = float(np.abs(g["D"][k]).max())
+        assert np.abs(D - g["D"][k]).max() <= rtol * dscale, (dtype, s, np.abs(D - g["D"][k]).max(), dscale)
+    p.close()
+
+
+@pytest.mark.parametrize("dtype,rtol", [("f32", 1e-4), ("bf16", 2e-2)])
+def test_sample_step_golden(dtype, rtol):
+    g = load_golden("sample_step_D9_H64_S10")
+    S = int(g["S"])
+    p = _plan(_sd(g), S, 20, dtype)
+    t = p.schedule()
+    for i in g["levels"]:
+        y = p.sample_step(int(i), float(t[i]), float(t[i + 1]), g[f"x_{i}"], g[f"eps_{i}"]).cpu().numpy()
+        ref = g[f"y_{i}"]
+        assert np.abs(y - ref).max() <= rtol * max(1.0, float(np.abs(ref).max())), (i, np.abs(y - ref).max())
+    p.close()
+
+
+# ------------------------------------------------------------------------------------------------ trajectories
+def _trajectory(name, dtype):
+    g = load_golden(name)
+    S, R = int(g["S"]), int(g["R"])
+    noise = g["noise"] if "noise" in g else golden_noise(g)
+    p = _plan(_sd(g), S, R, dtype)
+    out, tr = p.impute_sum(g["x_obs"], g["mask"], 1, noise=noise, trace=True)
+    torch.cuda.synchronize()
+    t = p.schedule()
+    p.close()
+    return g, out.cpu().numpy(), tr[:, 0].cpu().numpy(), t
+
+
+@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16", "impute_D9_H64_S50_N8",
+                                  "impute_D9_H1024_S50_N16", "impute_D64_H1024_S10_N32"])
+def test_impute_f32_per_step(name):
+    """north_star: per-step outputs within 1e-3 relative in fp32, identical noise."""
+    g, out, tr, t = _trajectory(name, "f32")
+    S, R = int(g["S"]), int(g["R"])
+    assert tr.shape[0] == (S - 1) * R + 1
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        lvl = min(int(k) // R, S - 1)
+        sig = float(t[lvl + 1]) if (int(k) % R == R - 1 or lvl == S - 1) else float(t[lvl])
+        rel_check(tr[k], ref, floor=max(1e-2 * sig, 1e-3), what=f"{name} iteration {k}")
+    rel_check(out, g["out"], floor=1e-3, what=f"{name} final")
+    obs = ~g["mask"]
+    assert np.array_equal(out[obs], g["x_obs"][obs]), "observed cells must come back bit-exactly"
+
+
+@pytest.mark.parametrize("name", ["impute_D9_H64_S50_N8", "impute_D9_H1024_S50_N16", "impute_D64_H1024_S10_N32"])
+def test_impute_bf16_trajectory(name):
+    """bf16 GEMM operands, fp32 state: looser bound (random gain-2 nets; see module docstring)."""
+    g, out, tr, t = _trajectory(name, "bf16")
+    R, S = int(g["R"]), int(g["S"])
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        lvl = min(int(k) // R, S - 1)
+        lim = 5e-2 * max(1.0, float(t[lvl]))
+        assert np.abs(tr[k] - ref).max() <= lim, (name, k, np.abs(tr[k] - ref).max(), lim)
+    assert np.abs(out - g["out"]).max() <= 5e-2, np.abs(out - g["out"]).max()
+    obs = ~g["mask"]
+    assert np.array_equal(out[obs], g["x_obs"][obs])
+
+
+def test_estep_trial_mean_golden():
+    from diffputer_amd.sampler import SamplerPlan  # noqa: F401
+    g = load_golden("estep_D9_H64_S5_T3")
+    n, d, S, R, T = (int(g[k]) for k in ("n", "d_in", "S", "R", "T"))
+    noise = np.stack([synth.reference_noise(int(s), synth.n_draws(S, R), (n, d)) for s in g["nseeds"]])
+    p = _plan(_sd(g), S, R, "f32")
+    x_obs = (g["X"] * (1.0 - g["mask"])).astype(np.float32)
+    # all three trials in one call ...
+    s3, _ = p.impute_sum(x_obs, g["mask"], T, noise=noise)
+    rel_check((s3 / T).cpu().numpy(), g["mean"], floor=1e-3, what="3 trials in one call")
+    # ... and one by one with accumulation (the order the reference sums in)
+    acc = torch.zeros(n, d, device=DEV)
+    for tr in range(T):
+        p.impute_sum(x_obs, g["mask"], 1, noise=noise[tr:tr + 1], out=acc, accumulate=tr > 0)
+    rel_check((acc / T).cpu().numpy(), g["mean"], floor=1e-3, what="accumulated trials")
+    assert torch.allclose(acc, s3, rtol=1e-6, atol=1e-6)
+    p.close()
+
+
+# ------------------------------------------------------------------------------------------------ Philox noise
+def _philox_numpy(ctr, key):
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [np.uint64(x) for x in ctr]
+    k = [np.uint64(x) for x in key]
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(M0) * c[0]
+        p1 = np.uint64(M1) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k[0]) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ c[3] ^ k[1]) & mask, p0 & mask]
+        k = [(k[0] + np.uint64(W0)) & mask, (k[1] + np.uint64(W1)) & mask]
+    return [int(x) for x in c]
+
+
+def test_philox_known_answer_and_box_muller():
+    from diffputer_amd.sampler import noise_field
+    # Random123 known-answer vector for philox4x32-10 (counter = key = 0)
+    assert _philox_numpy([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    seed, row_offset, trial, block, d = 0x1234567887654321, (1 << 33) + 5, 3, 17, 7
+    got = [noise_field(4, d, seed, row_offset, trial, block, comp, DEV).cpu().numpy() for comp in range(4)]
+    for r in range(4):
+        for c in range(d):
+            grow = row_offset + r
+            x = _philox_numpy([grow & 0xFFFFFFFF, grow >> 32, (trial << 16) | c, block], [seed & 0xFFFFFFFF, seed >> 32])
+            u = [((v >> 8) + 0.5) / 16777216.0 for v in x]
+            ra, rb = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
+            want = [ra * np.cos(2 * np.pi * u[1]), ra * np.sin(2 * np.pi * u[1]), rb * np.cos(2 * np.pi * u[3]), rb * np.sin(2 * np.pi * u[3])]
+            for comp in range(4):
+                assert abs(got[comp][r, c] - want[comp]) <= 2e-5 * max(1.0, abs(want[comp])), (r, c, comp)
+
+
+def test_philox_field_statistics():
+    from diffputer_amd.sampler import noise_field
+    z = torch.stack([noise_field(1 << 16, 16, 99, 0, 0, b, c, DEV) for b in (0, 1, 0xFFFFFFFF) for c in range(3)])
+    assert abs(float(z.mean())) < 2e-3 and abs(float(z.var()) - 1.0) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 5e-2
+    flat = z.reshape(z.shape[0], -1)
+    cc = torch.corrcoef(flat)
+    assert float((cc - torch.eye(cc.shape[0], device=cc.device)).abs().max()) < 5e-3     # fields are independent
+
+
+# ------------------------------------------------------------------------------------------------ properties at size
+def test_sharding_and_batching_invariance():
+    """Philox mode: the result for a row does not depend on which call / shard / trial batch computes it."""
+    d, hid, S, R, n, T = 9, 64, 4, 3, 700, 4
+    sd = synth.make_weights(d, hid, 77, 2.0)
+    X, mask = synth.make_table(n, d, seed=78)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    for dtype in ("f32", "bf16"):
+        p = _plan(sd, S, R, dtype)
+        whole, _ = p.impute_sum(x_obs, mask, T, seed=5)
+        again, _ = p.impute_sum(x_obs, mask, T, seed=5)
+        assert torch.equal(whole, again), "same seed must reproduce bit-exactly"
+        other, _ = p.impute_sum(x_obs, mask, T, seed=6)
+        assert not torch.equal(whole, other)
+        # two row shards with global row offsets, trials split 1 + 3
+        parts = []
+        for r0, r1 in ((0, 300), (300, n)):
+            acc = torch.zeros(r1 - r0, d, device=DEV)
+            p.impute_sum(x_obs[r0:r1], mask[r0:r1], 1, seed=5, row_offset=r0, trial_offset=0, out=acc, accumulate=False)
+            p.impute_sum(x_obs[r0:r1], mask[r0:r1], 3, seed=5, row_offset=r0, trial_offset=1, out=acc, accumulate=True)
+            parts.append(acc)
+        assert torch.equal(torch.cat(parts), whole), f"{dtype}: sharded result differs"
+        obs = torch.from_numpy(~mask).to(DEV)
+        assert torch.allclose(whole[obs], T * torch.from_numpy(x_obs).to(DEV)[obs], rtol=1e-6, atol=0)
+        p.close()
+
+
+def test_drop_in_api_matches_plan():
+    """impute_mask / sample_step with the reference's signatures, fed a torch Model like main.py:170-180."""
+    from diffputer_amd import diffusion_utils as du
+    from diffputer_amd.model import MLPDiffusion, Model
+    g = load_golden("impute_D9_H64_S5_N8")
+    sd = {k: torch.from_numpy(v) for k, v in _sd(g).items()}
+    model = Model(denoise_fn=MLPDiffusion(9, 64), hid_dim=9).to(DEV)
+    model.load_state_dict(sd)
+    net = model.denoise_fn_D
+    x = torch.from_numpy(g["x_obs"]).to(DEV)
+    m = torch.from_numpy(g["mask"])
+    out = du.impute_mask(net, x, m, 8, 9, 5, DEV, noise=g["noise"], dtype="f32")
+    rel_check(out.cpu().numpy(), g["out"], floor=1e-3, what="drop-in impute_mask")
+    assert out.dtype == torch.float32 and out.device.type == "cuda" and tuple(out.shape) == (8, 9)
+    # fresh noise per call when no seed is given, like the reference
+    a = du.impute_mask(net, x, m, 8, 9, 5, DEV)
+    b = du.impute_mask(net, x, m, 8, 9, 5, DEV)
+    assert not torch.equal(a, b)
+    # the torch forward of the mirrored modules agrees with the HIP denoiser
+    plan = du.plan_for(net, 5, DEV, "f32")
+    xs = torch.randn(32, 9, device=DEV)
+    with torch.no_grad():
+        want = net(xs, torch.tensor(0.7, device=DEV))
+    got = plan.denoise(xs, 0.7)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
+    s = du.sample(net, 64, 9, 5, DEV, seed=3, dtype="f32")
+    assert s.shape == (64, 9) and torch.isfinite(s).all()
+
+
+def test_errors_are_loud():
+    from diffputer_amd import _lib
+    from diffputer_amd.sampler import SamplerPlan
+    with pytest.raises(_lib.DiffputerError):
+        SamplerPlan({k: torch.from_numpy(v) for k, v in synth.make_weights(9, 96, 1).items()}, device=DEV)   # hid % 64 != 0
+    p = _plan(synth.make_weights(9, 64, 1), 5, 20, "f32")
+    with pytest.raises(ValueError):
+        p.impute_sum(np.zeros((4, 8), np.float32), np.zeros((4, 8), bool))          # wrong width
+    with pytest.raises(ValueError):
+        p.impute_sum(np.zeros((0, 9), np.float32), np.zeros((0, 9), bool))          # empty table
+    with pytest.raises(_lib.DiffputerError):
+        p.denoise(np.zeros((4, 9), np.float32), 0.0)                                # sigma must be > 0
+    p.close()

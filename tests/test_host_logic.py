@@ -1,0 +1,143 @@
+"""CPU tests: the C-ABI library loads and exports what include/diffputer.h declares (no compute
+calls without a GPU), host-side E-step logic, and the world_size-2 gather over gloo."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from diffputer_amd import _lib, estep, synth
+from diffputer_amd import model as dmodel
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    header = open(os.path.join(REPO, "include", "diffputer.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dp_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.dp_version.restype = ctypes.c_int
+    assert lib.dp_version() == 1
+
+
+def test_argument_errors_without_gpu():
+    """Argument validation that happens before any HIP call works on a CPU-only box."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.dp_last_error.restype = ctypes.c_char_p
+    h = ctypes.c_void_p()
+    assert lib.dp_plan_create(ctypes.byref(h), 9, 100, 50, 20, 1) == -1            # hid % 64 != 0
+    assert b"multiple of 64" in lib.dp_last_error()
+    assert lib.dp_plan_create(ctypes.byref(h), 0, 64, 50, 20, 1) == -1
+    assert lib.dp_plan_create(ctypes.byref(h), 9, 64, 1, 20, 1) == -1
+    assert lib.dp_plan_create(ctypes.byref(h), 9, 64, 50, 20, 7) == -1
+    assert h.value is None
+
+
+def test_no_cpu_fallback():
+    from diffputer_amd.sampler import SamplerPlan
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(9, 64, 0).items()}
+    with pytest.raises(_lib.DiffputerError):
+        SamplerPlan(sd, device="cpu")
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "diffputer_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("# checker only", ""), f
+
+
+def test_shard_bounds_cover_rows_exactly():
+    for n in (0, 1, 7, 8, 18389, 10_000_000):
+        for w in (1, 2, 4, 8):
+            spans = [estep.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_plan_calls_cover_rows_times_trials_once():
+    for n, T, mc in ((18389, 20, 65536), (100, 7, 65536), (200000, 3, 65536), (65536, 2, 65536), (5, 50, 8)):
+        seen = np.zeros((n, T), dtype=np.int32)
+        for r0, r1, t0, t1 in estep.plan_calls(n, T, mc):
+            assert (r1 - r0) * (t1 - t0) <= mc
+            seen[r0:r1, t0:t1] += 1
+        assert (seen == 1).all()
+
+
+def test_work_model_numbers():
+    assert dmodel.num_parameters(9, 1024) == 10_512_393                 # SURVEY.md §5 [probed]
+    assert dmodel.nfe_per_chain(50, 20) == 1961
+    assert dmodel.flops_per_row_eval(256, 1024) == 16_777_216 + 4096 * 256
+    assert abs(dmodel.nfe_per_chain(50, 20) * dmodel.flops_per_row_eval(256, 1024) / 3.4956e10 - 1) < 1e-4
+
+
+def test_mirrored_modules_keep_checkpoint_keys():
+    m = dmodel.Model(dmodel.MLPDiffusion(9, 64), hid_dim=9)
+    keys = list(m.state_dict().keys())
+    want = [synth.CKPT_PREFIX + f"{n}.{k}" for n, _, _ in synth.layer_shapes(9, 64) for k in ("weight", "bias")]
+    assert keys == want
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(9, 64, 3).items()})
+    loss = m(torch.randn(16, 9))
+    assert loss.ndim == 0 and torch.isfinite(loss)
+
+
+def test_mirrored_precond_matches_oracle():
+    from oracle import diffputer_oracle as orc
+    sd = synth.make_weights(12, 64, 4, 2.0)
+    m = dmodel.Model(dmodel.MLPDiffusion(12, 64), hid_dim=12)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = np.random.default_rng(0).standard_normal((10, 12)).astype(np.float32)
+    for s in (80.0, 1.3, 0.002):
+        with torch.no_grad():
+            got = m.denoise_fn_D(torch.from_numpy(x), torch.tensor(s)).numpy()
+        assert np.allclose(got, orc.precond(sd, x, np.float32(s)), rtol=1e-5, atol=1e-5)
+
+
+def test_synth_is_deterministic():
+    a, ma = synth.make_table(1000, 17, seed=5)
+    b, mb = synth.make_table(1000, 17, seed=5)
+    assert np.array_equal(a, b) and np.array_equal(ma, mb)
+    assert abs(float(ma.mean()) - 0.3) < 0.02 and abs(float(a.std()) - 0.5) < 0.02
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gather_worker(rank, world, port, n, d, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    full = torch.arange(n * d, dtype=torch.float32).reshape(n, d)
+    r0, r1 = estep.shard_bounds(n, world, rank)
+    got = estep.gather_rows(full[r0:r1].clone(), n)
+    q.put((rank, bool(torch.equal(got, full))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [11, 64])
+def test_gather_rows_world_size_2_gloo(n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
