@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- E-step imputation throughput on MI355X (BASELINE.json metric: imputed rows/sec,
+E-step, 50 steps x 10 trials).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full E-step pass (S=50 noise levels, R=20 resamples, Heun, T=10 trials -> 19 610
+denoiser evaluations per row) over one row shard of the synthetic 10M x 256 table of BASELINE.json
+configs[4].  The whole 10M-row table is ~1 h of MFMA work per GPU, so each step processes
+`--rows` rows of it per GPU (rows are independent chains; throughput in rows/s does not depend on
+the shard length once the GPU is full).  Inputs are resident in HBM before the timed region.
+Weak scaling: every rank takes its own `--rows` rows (global row offsets keep the Philox noise
+shard-invariant) and the per-step all-gather of the trial means is inside the timed region.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 256x256-tile bf16 MFMA
+GEMM that runs mlp.0 / mlp.2 / mlp.4): algorithmic FLOPs per launch / in-situ average launch
+duration from HIP events recorded on the launch stream during the timed steps (dp_plan_profile).
+`cpu_baseline` is the numpy oracle (a port of the reference algorithm) timed on this box's host
+cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from diffputer_amd import estep, synth                                   # noqa: E402
+from diffputer_amd.model import flops_per_row_eval, nfe_per_chain        # noqa: E402
+from diffputer_amd.sampler import SamplerPlan                            # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3        # f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
+
+
+def cpu_baseline(d, hid, S, R, T, rows, budget_note):
+    """The numpy oracle on the host cores: `rows` rows x 1 trial of the same workload."""
+    from oracle import diffputer_oracle as orc                            # the only place bench.py touches oracle/
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    sd = synth.make_weights(d, hid, seed=11, gain=1.0)
+    X, mask = synth.make_table(rows, d, seed=12)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+
+    class LazyNoise:                                                      # 3 924 x rows x d floats would not fit; draw on demand
+        def __init__(self):
+            self.rng = np.random.Generator(np.random.Philox(13))
+
+        def __getitem__(self, k):
+            return self.rng.standard_normal((rows, d), dtype=np.float32)
+
+    t0 = time.perf_counter()
+    orc.impute_mask(sd, x_obs, mask, LazyNoise(), S, R)
+    dt = time.perf_counter() - t0
+    row_trials_per_s = rows / dt
+    return {"value": row_trials_per_s / T, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} rows x 1 trial, full S={S}/R={R} schedule, D={d}, H={hid}, numpy float32 oracle "
+                      f"({dt:.1f} s; rows/s = row-trials/s / T={T}){budget_note}",
+            "row_trials_per_s": row_trials_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=8192, help="rows of the table per GPU per step")
+    ap.add_argument("--cols", type=int, default=256)
+    ap.add_argument("--hid", type=int, default=1024)
+    ap.add_argument("--num-steps", type=int, default=50)
+    ap.add_argument("--resample", type=int, default=20)
+    ap.add_argument("--trials", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--max-chains", type=int, default=1 << 16)
+    ap.add_argument("--cpu-rows", type=int, default=192, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    d, hid, S, R, T = a.cols, a.hid, a.num_steps, a.resample, a.trials
+    # random-init weights of the reference architecture (throughput is weight-independent), synthetic table shard
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(d, hid, seed=1, gain=1.0).items()}
+    plan = SamplerPlan(sd, num_steps=S, n_resample=R, dtype=a.dtype, device=dev)
+    X, mask = synth.make_table(a.rows, d, seed=1234 + rank)
+    Xd = torch.from_numpy(X).to(dev)
+    md = torch.from_numpy(mask).to(dev)
+    n_total = a.rows * world
+    row_offset = rank * a.rows
+
+    def one_step(step_idx):
+        local = estep.impute_trials(plan, Xd, md, T, seed=1000 + step_idx, row_offset=row_offset, max_chains=a.max_chains)
+        if world > 1:
+            return estep.gather_rows(local, n_total)
+        return local
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for w in range(a.warmup):
+        one_step(-1 - w)
+    if not a.no_profile:
+        evals_per_step = nfe_per_chain(S, R) * len(list(estep.plan_calls(a.rows, T, a.max_chains)))
+        plan.profile(max(1, (evals_per_step * a.steps) // 200))           # ~200 samples over the timed region
+    fence()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        out = one_step(k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    assert torch.isfinite(out).all(), "non-finite imputations"
+    obs = ~md
+    if world == 1:
+        assert torch.allclose(out[obs], Xd[obs], rtol=1e-6, atol=0), "observed cells must pass through"
+
+    rows_per_s = n_total * a.steps / dt
+    nfe = nfe_per_chain(S, R)
+    fl_row_eval = flops_per_row_eval(d, hid)
+    whole_tflops = rows_per_s * T * nfe * fl_row_eval / 1e12 / world      # per GPU
+    peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+
+    result = {
+        "metric": "imputed rows/sec (E-step, 50 steps x 10 trials)",
+        "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4]: synthetic 10M x {d} table, S={S} x R={R} x Heun, T={T} trials, "
+                               f"hid={hid}; each step = full E-step of a {a.rows}-row shard per GPU (MCAR 30%, random-init weights)",
+                   "rows_per_step_per_gpu": a.rows, "cols": d, "num_steps": S, "n_resample": R, "num_trials": T, "hid": hid,
+                   "chains_per_call": min(a.max_chains, a.rows * T), "parallelism": f"row-shard x{world}, all-gather of trial means"},
+        "row_trials_per_s": rows_per_s * T, "denoiser_row_evals_per_s": rows_per_s * T * nfe,
+        "whole_path": {"tflops_per_gpu": whole_tflops, "frac_of_mfma_peak": whole_tflops / peak,
+                       "flops_per_row": T * nfe * fl_row_eval},
+    }
+
+    if rank == 0 and not a.no_profile:
+        ms, cnt = plan.profile_read()
+        chains = min(a.max_chains, a.rows * T)
+        Mp = -(-chains // 256) * 256
+        H = hid
+        K1 = N5 = -(-d // 64) * 64
+        layer_flops = [2.0 * Mp * H * K1, 2.0 * Mp * 2 * H * H, 2.0 * Mp * 2 * H * 2 * H, 2.0 * Mp * H * 2 * H, 2.0 * Mp * N5 * H]
+        per = {}
+        names = ["gemm_proj", "gemm_mlp0", "gemm_mlp2", "gemm_mlp4", "gemm_mlp6", "step_mid", "step_end", "step_final"]
+        for i, nm in enumerate(names):
+            if cnt[i]:
+                per[nm] = {"avg_ms": ms[i] / cnt[i], "samples": cnt[i]}
+                if i < 5:
+                    per[nm]["tflops"] = layer_flops[i] / (ms[i] / cnt[i] * 1e-3) / 1e12
+        # dominant kernel: k_gemm_bf16<256,256,...,SiLU> = the mlp.0 / mlp.2 / mlp.4 launches (one of each per evaluation)
+        if all(cnt[i] for i in (1, 2, 3)):
+            avg_ms = sum(ms[i] / cnt[i] for i in (1, 2, 3)) / 3.0
+            avg_flops = sum(layer_flops[i] for i in (1, 2, 3)) / 3.0
+            ach = avg_flops / (avg_ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                  "kernel": "k_gemm_bf16<256,256,2,4,SiLU,bf16-out> (mlp.0, mlp.2, mlp.4)" if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
+                                  "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mp}
+        # fused step kernel (after the 2nd evaluation): algorithmic bytes per cell = x_hat r/w 8 + d_cur 4 + F 4 + x_obs 4 + mask 1 + u 2
+        if cnt[6]:
+            cells = chains * d
+            step_bytes = cells * (8 + 4 + 4 + 4 + 1 + (2 if a.dtype == "bf16" else 4))
+            gbs = step_bytes / (ms[6] / cnt[6] * 1e-3) / 1e9
+            result["fused_step"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                    "avg_launch_ms": ms[6] / cnt[6], "alg_bytes_per_launch": step_bytes}
+        result["kernels"] = per
+
+    if rank == 0 and a.gpus == 1 and a.cpu_rows > 0:
+        result["cpu_baseline"] = cpu_baseline(d, hid, S, R, T, a.cpu_rows, "")
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

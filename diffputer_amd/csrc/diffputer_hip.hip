@@ -53,8 +53,15 @@ struct dp_plan {
     float *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
     float *b_eff = nullptr;              // [(n_levels + 2), hid]; the last two rows are scratch for dp_denoise/dp_sample_step
     float *c_noise_dev = nullptr, *pe = nullptr, *hidden = nullptr;   // [(n_levels + 2)] / [.., hid] scratch
+    // optional in-situ kernel timing (dp_plan_profile): event pairs around sampled evaluations
+    int prof_stride = 0;                 // 0 = off; else every prof_stride-th evaluation is sampled
+    long prof_evals = 0;                 // evaluations seen since profiling was enabled
+    int prof_used = 0;                   // samples recorded
+    std::vector<hipEvent_t> prof_ev;     // DP_PROF_SAMPLES * 7 events: before GEMM-1, after GEMM-1..5, after the step kernel
+    std::vector<int> prof_tag;           // which step kernel followed: 0 mid, 1 end, 2 final
     size_t esize() const { return dtype == DP_DTYPE_BF16 ? 2 : 4; }
 };
+#define DP_PROF_SAMPLES 256
 
 namespace dp {
 
@@ -134,15 +141,33 @@ static Workspace carve(const dp_plan* p, int64_t M, void* base) {
 }
 
 // ---- one denoiser evaluation F(u, level): five GEMMs with fused epilogues (model.py:121-128) ---------------------
-static int eval_F(const dp_plan* p, const Workspace& w, const float* b_eff_row, hipStream_t st) {
+// `ev`: NULL, or 7 events of a profiling sample; [0..5] are recorded here, [6] by the caller after its step kernel.
+static int eval_F(const dp_plan* p, const Workspace& w, const float* b_eff_row, hipStream_t st, hipEvent_t* ev = nullptr) {
     const int H = p->hid, dt = p->dtype;
     int rc;
+#define DP_EV(i) do { if (ev) DP_HIP(hipEventRecord(ev[i], st)); } while (0)
+    DP_EV(0);
     if ((rc = gemm(dt, w.u, p->W[0], b_eff_row, w.actA, H, w.Mp, H, p->K1, 0, 0, st))) return rc;          // proj + emb (no act)
+    DP_EV(1);
     if ((rc = gemm(dt, w.actA, p->W[1], p->B[1], w.actB, 2 * H, w.Mp, 2 * H, H, 1, 0, st))) return rc;      // mlp.0 + SiLU
+    DP_EV(2);
     if ((rc = gemm(dt, w.actB, p->W[2], p->B[2], w.actA, 2 * H, w.Mp, 2 * H, 2 * H, 1, 0, st))) return rc;  // mlp.2 + SiLU
+    DP_EV(3);
     if ((rc = gemm(dt, w.actA, p->W[3], p->B[3], w.actB, H, w.Mp, H, 2 * H, 1, 0, st))) return rc;          // mlp.4 + SiLU
+    DP_EV(4);
     if ((rc = gemm(dt, w.actB, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;         // mlp.6 -> f32
+    DP_EV(5);
+#undef DP_EV
     return DP_OK;
+}
+
+// next profiling sample slot (7 events) if this evaluation is to be sampled, else NULL
+static hipEvent_t* prof_slot(dp_plan* p, int tag) {
+    if (!p->prof_stride) return nullptr;
+    const long k = p->prof_evals++;
+    if (k % p->prof_stride != 0 || p->prof_used >= DP_PROF_SAMPLES) return nullptr;
+    p->prof_tag[p->prof_used] = tag;
+    return &p->prof_ev[(size_t)7 * p->prof_used++];
 }
 
 // b_eff rows [first, first+count) from c_noise_dev[first..] (model.py:122-127)
@@ -169,6 +194,12 @@ static int check_plan(const dp_plan* p, bool need_weights) {
     DP_HIP(hipGetDevice(&dev));
     if (dev != p->device) return fail(DP_ESTATE, "plan belongs to device %d but device %d is current", p->device, dev);
     return DP_OK;
+}
+
+static void free_plan_events(dp_plan* p) {
+    for (auto e : p->prof_ev) (void)hipEventDestroy(e);
+    p->prof_ev.clear();
+    p->prof_stride = 0;
 }
 
 static void free_plan_buffers(dp_plan* p) {
@@ -234,6 +265,7 @@ int dp_plan_create(dp_plan** out, int d_in, int hid, int num_steps, int n_resamp
 void dp_plan_destroy(dp_plan* p) {
     if (!p) return;
     free_plan_buffers(p);
+    free_plan_events(p);
     delete p;
 }
 
@@ -327,21 +359,60 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
         const int j = it - i * R;
         const Level& l0 = p->lv[2 * i];
         const float h = p->t[i + 1] - p->th[i];
-        if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i) * H, st))) return rc;
+        hipEvent_t* ev = prof_slot(p, i < S - 1 ? 0 : 2);
+        if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i) * H, st, ev))) return rc;
         if (i < S - 1) {
             const Level& l1 = p->lv[2 * i + 1];
             hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
             DP_LAUNCH_CHECK("k_step_mid");
-            if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i + 1) * H, st))) return rc;
+            if (ev) DP_HIP(hipEventRecord(ev[6], st));
+            ev = prof_slot(p, 1);
+            if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i + 1) * H, st, ev))) return rc;
             const int add_re = j < R - 1;
             const int i_next = std::min((it + 1) / R, S - 1);
             hipLaunchKernelGGL(k_step_end, dim3(g), dim3(256), 0, st, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re,
                                p->churn[i_next], p->lv[2 * i_next].c.c_in);
             DP_LAUNCH_CHECK("k_step_end");
+            if (ev) DP_HIP(hipEventRecord(ev[6], st));
         } else {
             hipLaunchKernelGGL(k_step_final, dim3(grid_for(n_rows * D)), dim3(256), 0, st, c, it, l0.c.c_skip, l0.c.c_out, p->th[i], h, out,
                                (flags & DP_ACCUMULATE) ? 1 : 0);
             DP_LAUNCH_CHECK("k_step_final");
+            if (ev) DP_HIP(hipEventRecord(ev[6], st));
+        }
+    }
+    return DP_OK;
+}
+
+int dp_plan_profile(dp_plan* p, int stride) {
+    int rc = check_plan(p, false);
+    if (rc) return rc;
+    if (stride < 0) return fail(DP_EINVAL, "stride must be >= 0");
+    if (stride && p->prof_ev.empty()) {
+        p->prof_ev.resize((size_t)7 * DP_PROF_SAMPLES);
+        p->prof_tag.assign(DP_PROF_SAMPLES, 0);
+        for (auto& e : p->prof_ev) DP_HIP(hipEventCreate(&e));
+    }
+    p->prof_stride = stride;
+    p->prof_evals = 0;
+    p->prof_used = 0;
+    return DP_OK;
+}
+
+int dp_plan_profile_read(dp_plan* p, double ms_sum[8], int count[8]) {
+    int rc = check_plan(p, false);
+    if (rc) return rc;
+    if (!ms_sum || !count) return fail(DP_EINVAL, "NULL argument");
+    for (int k = 0; k < 8; ++k) { ms_sum[k] = 0.0; count[k] = 0; }
+    for (int s = 0; s < p->prof_used; ++s) {
+        hipEvent_t* ev = &p->prof_ev[(size_t)7 * s];
+        DP_HIP(hipEventSynchronize(ev[6]));
+        for (int k = 0; k < 6; ++k) {
+            float ms = 0.f;
+            DP_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            const int slot = k < 5 ? k : 5 + p->prof_tag[s];        // 0..4 GEMM-1..5, 5 step_mid, 6 step_end, 7 step_final
+            ms_sum[slot] += ms;
+            count[slot] += 1;
         }
     }
     return DP_OK;

@@ -120,6 +120,19 @@ class SamplerPlan:
             _lib.check(self.lib.dp_plan_embedding(self._h, out.ctypes.data_as(C.POINTER(C.c_float))), "dp_plan_embedding")
         return out
 
+    def profile(self, stride: int):
+        """Bracket every `stride`-th denoiser evaluation of later impute calls with HIP events (0 = off)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dp_plan_profile(self._h, int(stride)), "dp_plan_profile")
+
+    def profile_read(self):
+        """(ms_sum[8], count[8]) per kernel slot: 0..4 GEMM layers, 5 step_mid, 6 step_end, 7 step_final."""
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int * 8)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dp_plan_profile_read(self._h, ms, cnt), "dp_plan_profile_read")
+        return list(ms), list(cnt)
+
     # -- the sampler ---------------------------------------------------------------------------------------
     def _prep(self, x_obs, mask):
         x = torch.as_tensor(x_obs).to(self.device, torch.float32).contiguous()

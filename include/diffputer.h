@@ -131,6 +131,17 @@ int dp_plan_levels(const dp_plan* plan, float* sigma_out);
 int dp_plan_embedding(const dp_plan* plan, float* emb_out);
 
 /*
+ * In-situ kernel timing for bench.py (no counterpart in the reference).  dp_plan_profile(plan, stride) with
+ * stride > 0 makes dp_impute bracket every stride-th denoiser evaluation with HIP events on the caller's stream
+ * (at most 256 samples; stride = 0 switches it off).  dp_plan_profile_read waits for the recorded events and
+ * returns summed milliseconds and sample counts per kernel slot: 0..4 = the five GEMM layers (proj, mlp.0, mlp.2,
+ * mlp.4, mlp.6), 5 = step kernel after the first evaluation, 6 = step kernel after the second evaluation,
+ * 7 = final-level step kernel.
+ */
+int dp_plan_profile(dp_plan* plan, int stride);
+int dp_plan_profile_read(dp_plan* plan, double ms_sum[8], int count[8]);
+
+/*
  * Single-kernel test entry: out[M, N] = act(A[M, K] @ W[N, K]^T + bias[N]) with the plan-independent GEMM
  * kernels (model.py:102-111 are five such layers).  dtype as above: for DP_DTYPE_BF16, A and W are bf16
  * (uint16 bit patterns) and out is bf16 unless out_f32 != 0; for DP_DTYPE_F32 everything is float32.
