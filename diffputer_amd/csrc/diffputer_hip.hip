@@ -8,6 +8,7 @@
 
 #include "dp_embed.h"
 #include "dp_gemm_bf16.h"
+#include "dp_gemm_bf16_pp.h"
 #include "dp_gemm_f32.h"
 #include "dp_philox.h"
 #include "dp_step.h"
@@ -70,7 +71,34 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// ---- GEMM dispatch ---------------------------------------------------------------------------------------------
+// tuning knob (dp_tune "gemm_variant"): 2 = ping-pong kernel for the wide layers (default), 1 = k_gemm_bf16 everywhere
+static int g_gemm_variant = 2;
+
+static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
+                          int act, int out_f32, hipStream_t st) {
+    const int nbn = N / PP_BN;
+    const int64_t nwg64 = (M / PP_BM) * nbn;
+    if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
+    const int nwg = (int)nwg64;
+#define DP_GO(ACT, OF)                                                                                              \
+    do {                                                                                                            \
+        auto kern = k_gemm_bf16_pp<ACT, OF>;                                                                        \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) {                                                                                           \
+            DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES)); \
+            attr_done = true;                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(PP_THREADS), PP_LDS_BYTES, st, A, W, bias, out, ldo, K, nbn, nwg); \
+    } while (0)
+    if (act && !out_f32) DP_GO(true, false);
+    else if (!act && !out_f32) DP_GO(false, false);
+    else if (!act && out_f32) DP_GO(false, true);
+    else DP_GO(true, true);
+#undef DP_GO
+    DP_LAUNCH_CHECK("k_gemm_bf16_pp");
+    return DP_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_bf16_cfg(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
                            int act, int out_f32, hipStream_t st) {
@@ -103,6 +131,8 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
     if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
+        if (N % 256 == 0 && K >= 2 * PP_BK && g_gemm_variant == 2)
+            return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         if (N % 256 == 0)
             return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         return launch_bf16_cfg<256, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
@@ -518,6 +548,16 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
     if (!A || !W || !bias || !out) return fail(DP_EINVAL, "NULL argument");
     if (dtype == DP_DTYPE_F32) out_f32 = 1;
     return gemm(dtype, A, W, bias, out, N, M, N, K, act ? 1 : 0, out_f32 ? 1 : 0, (hipStream_t)stream);
+}
+
+int dp_tune(const char* key, int value) {
+    if (!key) return fail(DP_EINVAL, "key is NULL");
+    if (!strcmp(key, "gemm_variant")) {
+        if (value < 1 || value > 2) return fail(DP_EINVAL, "gemm_variant must be 1 or 2");
+        g_gemm_variant = value;
+        return DP_OK;
+    }
+    return fail(DP_EINVAL, "unknown tuning key '%s'", key);
 }
 
 int dp_noise_field(float* out, int64_t n_rows, int d_in, uint64_t seed, uint64_t row_offset, int trial, uint32_t block, int comp,

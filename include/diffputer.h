@@ -151,6 +151,13 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
               int64_t M, int N, int K, int act, int out_f32, void* stream);
 
 /*
+ * Process-wide tuning knob for benchmarks and A/B tools (no counterpart in the reference; results are
+ * identical for every setting).  Keys: "gemm_variant" = 2 ping-pong 256x256 kernel for the wide layers (default),
+ * 1 = the simple double-buffered kernel everywhere.
+ */
+int dp_tune(const char* key, int value);
+
+/*
  * Fill out[n_rows, d_in] with the Philox Gaussian field of draw block `block`, component `comp` (0..3), for
  * global rows row_offset.. and global trial `trial` (the noise dp_impute uses when noise == NULL).
  * No counterpart in the reference (it uses torch's global RNG, unseeded).
