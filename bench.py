@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=8192, help="rows of the table per GPU per step")
+    ap.add_argument("--rows", type=int, default=32768, help="rows of the table per GPU per step")
     ap.add_argument("--cols", type=int, default=256)
     ap.add_argument("--hid", type=int, default=1024)
     ap.add_argument("--num-steps", type=int, default=50)

@@ -74,21 +74,30 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
 // tuning knob (dp_tune "gemm_variant"): 2 = ping-pong kernel for the wide layers (default), 1 = k_gemm_bf16 everywhere
 static int g_gemm_variant = 2;
 
+static int g_num_cus = 0;       // CUs of the current device: the persistent kernel runs one workgroup per CU
+
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
                           int act, int out_f32, hipStream_t st) {
     const int nbn = N / PP_BN;
     const int64_t nwg64 = (M / PP_BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        DP_HIP(hipGetDevice(&dev));
+        DP_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus = prop.multiProcessorCount;
+    }
 #define DP_GO(ACT, OF)                                                                                              \
     do {                                                                                                            \
         auto kern = k_gemm_bf16_pp<ACT, OF>;                                                                        \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
-            DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES)); \
+            DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL)); \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(PP_THREADS), PP_LDS_BYTES, st, A, W, bias, out, ldo, K, nbn, nwg); \
+        hipLaunchKernelGGL(kern, dim3(std::min(nwg, g_num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg); \
     } while (0)
     if (act && !out_f32) DP_GO(true, false);
     else if (!act && !out_f32) DP_GO(false, false);
@@ -131,7 +140,7 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
     if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
-        if (N % 256 == 0 && K >= 2 * PP_BK && g_gemm_variant == 2)
+        if (N % 256 == 0 && K >= 3 * PP_BK && g_gemm_variant == 2)
             return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         if (N % 256 == 0)
             return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
@@ -549,6 +558,14 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
     if (dtype == DP_DTYPE_F32) out_f32 = 1;
     return gemm(dtype, A, W, bias, out, N, M, N, K, act ? 1 : 0, out_f32 ? 1 : 0, (hipStream_t)stream);
 }
+
+#ifdef DP_PP_STAMP
+// diagnostic build only: where the ping-pong kernel writes its stamps (device pointer, [grid][16][2][8] u64) or NULL
+int dp_debug_stamps(void* buf) {
+    DP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dp::g_pp_stamp_buf), &buf, sizeof buf));
+    return DP_OK;
+}
+#endif
 
 int dp_tune(const char* key, int value) {
     if (!key) return fail(DP_EINVAL, "key is NULL");

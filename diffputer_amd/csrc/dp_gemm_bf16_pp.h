@@ -17,6 +17,10 @@
 //   * phase = { ds_reads ; stage ; s_waitcnt vmcnt(8) ; s_barrier ; lgkmcnt(0) ; 16 MFMA ; s_barrier }.  The four
 //     waves of wave row 1 run one barrier behind those of wave row 0, so on every SIMD one wave is in its MFMA
 //     segment while its partner reads LDS and issues DMA.
+//   * the workgroup is PERSISTENT (one per CU: it owns the whole 160 KiB of LDS) and walks output tiles
+//     tile = round * gridDim + xcd_remap(blockIdx); the prologue DMA of the next tile is issued BEFORE the epilogue
+//     of the current one, so the epilogue's SiLU, its stores and their drain hide under the next tile's first
+//     loads instead of leaving the chip idle while every CU stores at once.
 // Hazards (barrier instances b1, b2, ...; row 0 runs [R_P S_P W_P] b(2P+1) [M_P] b(2P+2), row 1 one barrier later):
 //   RAW  a half-tile read in phase Q was staged in phase <= Q-5; the vmcnt(8) of phase Q-1 (issued after that
 //        phase's stage) leaves only the four newest half-tiles in flight, and every wave has passed that wait
@@ -31,47 +35,85 @@
 namespace dp {
 
 #define DP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define DP_VMCNT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define DP_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// 32-bit LDS byte address of a pointer into __shared__ memory (operand of inline-asm ds_* instructions)
+__device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(size_t)(DP_LDS_AS const char*)p; }
 
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_THREADS = 512;
 constexpr int PP_HALF = 16384;                                  // bytes of one half-tile
 constexpr int PP_LDS_BYTES = 8 * PP_HALF;                       // 2 K-tile buffers x {A0, A1, B0, B1}
+#ifndef PP_TAIL
+#define PP_TAIL 0
+#endif
+constexpr int PP_STAGE_WAVE = 4096;                             // epilogue staging per wave (32 rows x 128 B)
+constexpr int PP_LDS_TOTAL = PP_LDS_BYTES + 8 * PP_STAGE_WAVE;  // 160 KiB: the whole LDS of a CU
+
+// Diagnostic build only (-DDP_PP_STAMP, tools/pp_stamps.py): s_memtime / s_memrealtime stamps per workgroup and round,
+// written to a buffer of their own; no stamp executes in the shipped library.
+#ifdef DP_PP_STAMP
+__device__ unsigned long long* g_pp_stamp_buf = nullptr;        // [gridDim][16 rounds][8]
+#define PP_STAMP(k)                                                                                             \
+    do {                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[k]) :: "memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
 
 template <bool ACT, bool OUT_F32>
 __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int ldo, int K, int nbn, int nwg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // vector-memory instructions one wave's epilogue issues (they sit between the next tile's prologue DMA and its
+    // phase DMA in the in-order vmcnt queue)
+    constexpr int NST = OUT_F32 ? 32 : 16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (t / nbn) * PP_BM, n0 = (t % nbn) * PP_BN;
-    const int nk = K / PP_BK;                                   // host guarantees nk >= 2
+    const int G = gridDim.x;
+    const int nk = K / PP_BK;                                   // host guarantees nk >= 3
 
     // ---- staging: a wave moves pieces `wave` and `wave + 8` of every half-tile (a piece = 8 rows x 128 B) ----
     //   A half h, piece p: half-local rows 8p.. = wave row p/8, rows h*64 + (p%8)*8 ..  of that wave row's 128
     //   B half h, piece p: half-local rows 8p.. = wave col p/4, cols h*32 + (p%4)*8 ..  of that wave col's 64
+    // Source addresses are a wave-uniform base (SGPRs) + a 32-bit per-lane byte offset, so the eight DMA streams share
+    // two address VGPRs.
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const bf16_t* a_src = A + (size_t)(m0 + wave * 8 + srow) * K + schunk * 8;                       // h = 0, piece `wave`
-    const bf16_t* w_src = W + (size_t)(n0 + (wave >> 2) * 64 + (wave & 3) * 8 + srow) * K + schunk * 8;
-    const size_t a_p2 = (size_t)128 * K, a_h = (size_t)64 * K;   // second piece = other wave row; half 1 = +64 rows
-    const size_t w_p2 = (size_t)128 * K, w_h = (size_t)32 * K;   // second piece = wave col + 2;   half 1 = +32 cols
+    const unsigned a_voff = (unsigned)(((wave * 8 + srow) * K + schunk * 8) * 2);                     // h = 0, piece `wave`
+    const unsigned w_voff = (unsigned)((((wave >> 2) * 64 + (wave & 3) * 8 + srow) * K + schunk * 8) * 2);
+    const size_t a_p2 = (size_t)256 * K, a_h = (size_t)128 * K;  // bytes: second piece = other wave row (+128 rows); half 1 = +64 rows
+    const size_t w_p2 = (size_t)256 * K, w_h = (size_t)64 * K;   // bytes: second piece = wave col + 2 (+128 cols); half 1 = +32 cols
     char* const lds_piece = smem + wave * 1024;
+    const char *a_base, *w_base;                                 // wave-uniform: first byte of the tile's A rows / W rows
 
     // slot of (buffer b, operand o, half h) = ((b * 2 + o) * 2 + h) * 16 KiB
     auto stage_a = [&](int kt, int h) {
         char* dst = lds_piece + ((kt & 1) * 4 + h) * PP_HALF;
-        const bf16_t* src = a_src + h * a_h + (size_t)kt * PP_BK;
-        glds16(src, dst);
-        glds16(src + a_p2, dst + 8192);
+        const char* src = a_base + h * a_h + (size_t)kt * (PP_BK * 2);
+        unsigned vo = a_voff;
+        asm volatile("" : "+v"(vo));                             // keep base + offset un-hoisted: selects the saddr + voffset form
+        glds16(src + vo, dst);
+        glds16(src + a_p2 + vo, dst + 8192);
     };
     auto stage_b = [&](int kt, int h) {
         char* dst = lds_piece + ((kt & 1) * 4 + 2 + h) * PP_HALF;
-        const bf16_t* src = w_src + h * w_h + (size_t)kt * PP_BK;
-        glds16(src, dst);
-        glds16(src + w_p2, dst + 8192);
+        const char* src = w_base + h * w_h + (size_t)kt * (PP_BK * 2);
+        unsigned vo = w_voff;
+        asm volatile("" : "+v"(vo));
+        glds16(src + vo, dst);
+        glds16(src + w_p2 + vo, dst + 8192);
+    };
+    // prologue DMA of a tile: half-tiles in staging order A0(0) B0(0) B1(0) A1(0) A0(1) B0(1)
+    auto prologue = [&](int m0, int n0) {
+        a_base = (const char*)A + (size_t)m0 * K * 2;
+        w_base = (const char*)W + (size_t)n0 * K * 2;
+        stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1); stage_a(1, 0); stage_b(1, 0);
     };
 
     // ---- fragment reads: row (lane&15) of a 16-row tile, chunk ks*4 + lane/16, swizzled ----
@@ -79,24 +121,14 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     const int a_rd = wm * 8192 + foff;                           // + i * 2048 (m-tile i of the half), ^ 64 for ks = 1
     const int b_rd = 2 * PP_HALF + wn * 4096 + foff;             // + j * 2048 (n-tile j of the half)
 
-    f32x4 acc[2][4][2][2];                                       // [A half][m-tile][B half][n-tile]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 af[2][4], bf0[2][2], bf1[2][2];                       // [ks][tile]
-
 #define PP_READ_A(buf, h)                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)              \
         af[ks][i] = *(const bf16x8*)((buf) + (h) * PP_HALF + ((a_rd + i * 2048) ^ (ks * 64)))
 #define PP_READ_B(dst, buf, h)                                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
         dst[ks][j] = *(const bf16x8*)((buf) + (h) * PP_HALF + ((b_rd + j * 2048) ^ (ks * 64)))
+    // The closing barrier sits PP_TAIL MFMAs before the end of the cluster: barriers order LDS reads and DMA issue,
+    // not the register-only MFMAs, and the partner wave's hand-off latency then hides under this wave's last MFMAs.
 #define PP_MFMA(ha, hb, bfr)                                                                                    \
     do {                                                                                                        \
         __builtin_amdgcn_s_barrier();                                                                           \
@@ -104,80 +136,197 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                          \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                     \
+                if (ks * 8 + i * 2 + j == 16 - PP_TAIL) {                                                       \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                    __builtin_amdgcn_s_barrier();                                                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
+                }                                                                                               \
                 acc[ha][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[ha][i][hb][j], 0, 0, 0); \
+            }                                                                                                   \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        __builtin_amdgcn_s_barrier();                                                                           \
+        if (PP_TAIL == 0) __builtin_amdgcn_s_barrier();                                                         \
     } while (0)
-
-    // ---- prologue: half-tiles in staging order A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) ----
-    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1); stage_a(1, 0); stage_b(1, 0);
-    DP_VMCNT(8);                                                 // A0(0), B0(0) have landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                   // wave row 1 runs one barrier behind
-
     // One K-tile.  ST1: tile kt+1 exists (stage B1, A1 of it); ST2: tile kt+2 exists (stage A0, B0 of it).
-    // V0..V3: vmcnt after the stage of phase c (8 in steady state; smaller in the tail where stages are skipped).
-#define PP_TILE(kt, ST1, ST2, V0, V1, V2, V3)                                                                   \
+    // WAIT(c): the vmcnt after the stage of phase c.
+#define PP_TILE(kt, ST1, ST2, WAIT)                                                                             \
     do {                                                                                                        \
         const char* buf = smem + ((kt) & 1) * 4 * PP_HALF;                                                      \
         /* c0 */                                                                                                \
         PP_READ_B(bf0, buf, 0);                                                                                 \
         PP_READ_A(buf, 0);                                                                                      \
         if (ST1) stage_b((kt) + 1, 1);                                                                          \
-        DP_VMCNT(V0);                                                                                           \
+        WAIT(0);                                                                                                \
         PP_MFMA(0, 0, bf0);                                                                                     \
         /* c1 */                                                                                                \
         PP_READ_B(bf1, buf, 1);                                                                                 \
         if (ST1) stage_a((kt) + 1, 1);                                                                          \
-        DP_VMCNT(V1);                                                                                           \
+        WAIT(1);                                                                                                \
         PP_MFMA(0, 1, bf1);                                                                                     \
         /* c2 */                                                                                                \
         PP_READ_A(buf, 1);                                                                                      \
         if (ST2) stage_a((kt) + 2, 0);                                                                          \
-        DP_VMCNT(V2);                                                                                           \
+        WAIT(2);                                                                                                \
         PP_MFMA(1, 1, bf1);                                                                                     \
         /* c3 */                                                                                                \
         if (ST2) stage_b((kt) + 2, 0);                                                                          \
-        DP_VMCNT(V3);                                                                                           \
+        WAIT(3);                                                                                                \
         PP_MFMA(1, 0, bf0);                                                                                     \
     } while (0)
+    // steady state: leave the four newest half-tiles in flight.  During K-tile 0 of a tile whose prologue was issued
+    // ahead of the previous epilogue, that epilogue's NST stores sit behind the prologue DMA in the queue.
+#define PP_WAIT_MAIN(c) DP_VMCNT(8)
+#define PP_WAIT_T0(c) DP_VMCNT_N(8 + NST)                                                        /* K-tile 0 behind an epilogue */
+#define PP_WAIT_T2(c) do { if ((c) < 3) { DP_VMCNT(8); } else { DP_VMCNT(4); } } while (0)       /* tile nk-2 */
+#define PP_WAIT_T1(c) do { if ((c) == 0) { DP_VMCNT(2); } else { DP_VMCNT(0); } } while (0)      /* tile nk-1 */
 
-    int kt = 0;
-    for (; kt < nk - 2; ++kt) PP_TILE(kt, true, true, 8, 8, 8, 8);
-    // tile nk-2: its c2/c3 stages do not exist; in flight after c1 are A0,B0,B1,A1 of tile nk-1
-    PP_TILE(kt, true, false, 8, 8, 8, 4);                        // c3: A0(nk-1), B0(nk-1) must land -> 2 newer half-tiles
-    ++kt;
-    PP_TILE(kt, false, false, 2, 0, 0, 0);                       // c0: B1(nk-1) must land -> 1 newer; c1: A1(nk-1)
-    if (wm == 0) __builtin_amdgcn_s_barrier();                   // balance wave row 1's extra barrier
+    // tile coordinates live in SGPRs (integer division runs on the VALU: read the result back)
+    auto tile_m0 = [&](int tile) { return __builtin_amdgcn_readfirstlane((tile / nbn) * PP_BM); };
+    auto tile_n0 = [&](int tile) { return __builtin_amdgcn_readfirstlane((tile % nbn) * PP_BN); };
+    int tile = xcd_remap(blockIdx.x, G);                         // host guarantees G <= nwg
+    int m0 = tile_m0(tile), n0 = tile_n0(tile);
+    prologue(m0, n0);
+    bool first = true;
 
+#ifdef DP_PP_STAMP
+    unsigned long long stamp[5];
+    int round = 0;
+#endif
+    for (;;) {
+        PP_STAMP(0);
+        f32x4 acc[2][4][2][2];                                   // [A half][m-tile][B half][n-tile]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[2][4], bf0[2][2], bf1[2][2];                   // [ks][tile]
+
+        // A0(0), B0(0) have landed (this wave's pieces): all but the 4 newer half-tiles (and the epilogue's stores)
+        if (first) { DP_VMCNT(8); } else { DP_VMCNT_N(8 + NST); }
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();               // wave row 1 runs one barrier behind
+        PP_STAMP(1);
+
+        if (first) PP_TILE(0, true, true, PP_WAIT_MAIN);
+        else PP_TILE(0, true, true, PP_WAIT_T0);
+        int kt = 1;
+#pragma clang loop unroll(disable)
+        for (; kt < nk - 2; ++kt) PP_TILE(kt, true, true, PP_WAIT_MAIN);
+        PP_TILE(kt, true, false, PP_WAIT_T2);                    // c3: A0, B0 of tile nk-1 must land -> 2 newer half-tiles
+        ++kt;
+        PP_TILE(kt, false, false, PP_WAIT_T1);                   // c0: B1(nk-1) must land -> 1 newer; c1: A1(nk-1)
+        if (wm == 0) __builtin_amdgcn_s_barrier();               // balance wave row 1's extra barrier: LDS is quiescent
+        PP_STAMP(2);
+
+        // ---- epilogue: lane holds out[m = lane&15][n = 4*(lane>>4) + 0..3] of each 16x16 tile ----
+        int elane = lane;                                        // opaque copy: keeps the epilogue's lane-dependent address
+        asm volatile("" : "+v"(elane));                          // arithmetic from being hoisted across the K loop (VGPRs)
+        const int en = n0 + wn * 64 + (elane >> 4) * 4;
+        float4 bv[2][2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[hb][j] = *(const float4*)(bias + en + hb * 32 + j * 16);
+        // materialise the bias NOW (one wait for the four loads): a later compiler-placed wait for them would be a
+        // vmcnt(0) that drains the next tile's prologue DMA
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                asm volatile("" : "+v"(bv[hb][j].x), "+v"(bv[hb][j].y), "+v"(bv[hb][j].z), "+v"(bv[hb][j].w));
+        const int om = m0 + wm * 128, on = n0 + wn * 64;
+
+        tile += G;
+        const bool more = tile < nwg;
+        if (more) {
+            m0 = tile_m0(tile);
+            n0 = tile_n0(tile);
+            prologue(m0, n0);
+        }
+
+        if (OUT_F32) {
+            float* const orow = (float*)out + (size_t)(om + (elane & 15)) * ldo + on + (elane >> 4) * 4;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 c = acc[ha][i][hb][j];
+                            float v0 = c[0] + bv[hb][j].x, v1 = c[1] + bv[hb][j].y, v2 = c[2] + bv[hb][j].z, v3 = c[3] + bv[hb][j].w;
+                            if (ACT) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                            *(float4*)(orow + (size_t)(ha * 64 + i * 16) * ldo + hb * 32 + j * 16) = make_float4(v0, v1, v2, v3);
+                        }
+        } else {
+            // bf16: a lane's 8-byte pieces would make 32-B store segments; transpose 32 rows at a time through this
+            // wave's private 4-KiB staging area (128-B rows, 16-B chunk c of row r at c ^ (r&7)) and store whole
+            // 128-B rows, 16 B per lane.  The LDS accesses are inline asm: for a compiler-visible ds_write hipcc
+            // first drains every LDS-DMA in flight (vmcnt(0)), i.e. the next tile's prologue.  Same-wave LDS
+            // operations execute in issue order, so the only wait is the one that ends the read statement.
+            const unsigned stg = lds_u32(smem) + PP_LDS_BYTES + wave * PP_STAGE_WAVE;
+            const int wr = elane & 15, wq = elane >> 4;           // write side: row within the 16-row tile, 4-column group
+            const int rr = elane >> 3, rc = elane & 7;            // read side: row within an 8-row group, 16-B chunk
+            // write address of 8-byte unit u = hb*8 + j*4 + wq of row wr: chunk (u>>1) ^ (wr&7), half u&1
+            const unsigned wa = stg + wr * 128 + ((((wq >> 1) ^ (wr & 7))) << 4) + (wq & 1) * 8;
+            const unsigned ra = stg + rr * 128 + ((rc ^ rr) << 4);                         // rows rr + 8s: + 1024 s
+            bf16_t* const orow = (bf16_t*)out + (size_t)(om + rr) * ldo + on + rc * 8;
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const f32x4 c = acc[ha][ip * 2 + ii][hb][j];
+                                float v0 = c[0] + bv[hb][j].x, v1 = c[1] + bv[hb][j].y, v2 = c[2] + bv[hb][j].z, v3 = c[3] + bv[hb][j].w;
+                                if (ACT) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                                const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                                const unsigned addr = wa ^ ((hb * 4 + j * 2) << 4);
+                                if (ii == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pk) : "memory");
+                                else asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(addr), "v"(pk) : "memory");
+                            }
+                    uint4 r0, r1, r2, r3;
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(ra) : "memory");
+                    bf16_t* const o = orow + (size_t)(ha * 64 + ip * 32) * ldo;
+                    *(uint4*)(o) = r0;
+                    *(uint4*)(o + (size_t)8 * ldo) = r1;
+                    *(uint4*)(o + (size_t)16 * ldo) = r2;
+                    *(uint4*)(o + (size_t)24 * ldo) = r3;
+                }
+        }
+#ifdef DP_PP_STAMP
+        PP_STAMP(3);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[4]) :: "memory");
+        if (g_pp_stamp_buf && round < 16 && (tid & 255) == 0) {                     // wave 0 and wave 4 (one per wave row)
+            unsigned long long* d = g_pp_stamp_buf + (((size_t)blockIdx.x * 16 + round) * 2 + (tid >> 8)) * 8;
+            for (int k = 0; k < 5; ++k) d[k] = stamp[k];
+        }
+        ++round;
+#endif
+        if (!more) break;
+        first = false;
+    }
+
+#undef PP_WAIT_MAIN
+#undef PP_WAIT_T0
+#undef PP_WAIT_T2
+#undef PP_WAIT_T1
 #undef PP_TILE
 #undef PP_MFMA
 #undef PP_READ_A
 #undef PP_READ_B
-
-    // ---- epilogue: lane holds out[m = lane&15][n = 4*(lane>>4) + 0..3] of each 16x16 tile ----
-    const int em = m0 + wm * 128 + (lane & 15);
-    const int en = n0 + wn * 64 + (lane >> 4) * 4;
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = en + hb * 32 + j * 16;
-            const float4 bv = *(const float4*)(bias + n);
-#pragma unroll
-            for (int ha = 0; ha < 2; ++ha)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 c = acc[ha][i][hb][j];
-                    float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
-                    if (ACT) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
-                    const size_t o = (size_t)(em + ha * 64 + i * 16) * ldo + n;
-                    if (OUT_F32) *(float4*)((float*)out + o) = make_float4(v0, v1, v2, v3);
-                    else *(uint2*)((bf16_t*)out + o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                }
-        }
 }
 
 }  // namespace dp

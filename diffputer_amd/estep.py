@@ -36,6 +36,7 @@ def plan_calls(n_rows: int, num_trials: int, max_chains: int):
                 yield r0, min(n_rows, r0 + max_chains), t, t + 1
     else:
         per = max(1, max_chains // n_rows)
+        per = -(-num_trials // -(-num_trials // per))                      # same number of calls, equal sizes
         for t0 in range(0, num_trials, per):
             yield 0, n_rows, t0, min(num_trials, t0 + per)
 

@@ -1,0 +1,7 @@
+#!/bin/sh
+# Diagnostic build of the library with in-kernel stamps (never loaded by the package, tests or bench.py).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p tools/diag
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -DDP_PP_STAMP \
+    -o tools/diag/libdiffputer_hip_stamp.so diffputer_amd/csrc/diffputer_hip.hip

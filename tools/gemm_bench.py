@@ -21,11 +21,15 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--only", default=None)
+ap.add_argument("--act", type=int, default=1)
+ap.add_argument("--shapes", default=None, help="extra shapes as N:K,N:K (replaces the default list)")
 a = ap.parse_args()
 lib = _lib.load()
 dev = "cuda:0"
 variants = [int(v) for v in a.variants.split(",")]
 shapes = [("mlp.0", 2048, 1024), ("mlp.2", 2048, 2048), ("mlp.4", 1024, 2048), ("proj256", 1024, 256), ("mlp.6/256", 256, 1024)]
+if a.shapes:
+    shapes = [(f"N{n}K{k}", int(n), int(k)) for n, k in (x.split(":") for x in a.shapes.split(","))]
 g = torch.Generator(device=dev).manual_seed(0)
 for name, N, K in shapes:
     if a.only and name != a.only:
@@ -38,12 +42,12 @@ for name, N, K in shapes:
     for r in range(a.rounds):
         for v in variants:
             _lib.check(lib.dp_tune(b"gemm_variant", v), "dp_tune")
-            o = linear(A, W, b, act=True)
+            o = linear(A, W, b, act=bool(a.act))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                o = linear(A, W, b, act=True)
+                o = linear(A, W, b, act=bool(a.act))
             e1.record()
             torch.cuda.synchronize()
             res[v].append(2.0 * a.m * N * K * a.iters / (e0.elapsed_time(e1) * 1e-3) / 1e12)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Where a ping-pong GEMM workgroup spends its time: s_memtime stamps from the diagnostic build.
+
+    hipcc ... -DDP_PP_STAMP -o tools/diag/libdiffputer_hip_stamp.so diffputer_amd/csrc/diffputer_hip.hip   (tools/build_diag.sh)
+    python tools/pp_stamps.py [--m 65536 --n 2048 --k 2048]
+Stamps per workgroup and round: 0 tile start, 1 prologue landed (first barrier passed), 2 K loop done, 3 epilogue issued;
+4 = s_memrealtime (100 MHz) at 3.  Shares, not absolute times, are the result (the stamps fence the schedule).
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=65536)
+ap.add_argument("--n", type=int, default=2048)
+ap.add_argument("--k", type=int, default=2048)
+ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+lib = C.CDLL(os.path.join(REPO, "tools", "diag", "libdiffputer_hip_stamp.so"))
+lib.dp_last_error.restype = C.c_char_p
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(0)
+A = torch.randn(a.m, a.k, device=dev, generator=g).bfloat16()
+W = (torch.randn(a.n, a.k, device=dev, generator=g) / a.k ** 0.5).bfloat16()
+b = torch.randn(a.n, device=dev, generator=g)
+out = torch.empty(a.m, a.n, device=dev, dtype=torch.bfloat16)
+grid = 256
+buf = torch.zeros(grid * 16 * 2 * 8, dtype=torch.int64, device=dev)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def run():
+    rc = lib.dp_linear(1, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()),
+                       C.c_int64(a.m), a.n, a.k, 1, 0, st)
+    assert rc == 0, lib.dp_last_error()
+
+
+for _ in range(a.iters):
+    run()
+torch.cuda.synchronize()
+assert lib.dp_debug_stamps(C.c_void_p(buf.data_ptr())) == 0
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+s = buf.cpu().numpy().reshape(grid, 16, 2, 8).astype(np.float64)
+rounds = int((s[0, :, 0, 0] > 0).sum())
+print(f"M={a.m} N={a.n} K={a.k}: launch {ms*1e3:.1f} us = {2.0*a.m*a.n*a.k/ms/1e9:.1f} TFLOP/s, rounds {rounds}")
+t0_all = s[:, 0, 0, 0].min()
+for r in range(rounds):
+    d = s[:, r]                                                       # [grid, 2 wave rows, 8]
+    pro = d[:, :, 1] - d[:, :, 0]
+    loop = d[:, :, 2] - d[:, :, 1]
+    epi = d[:, :, 3] - d[:, :, 2]
+    start = d[:, 0, 0] - t0_all
+    print(f"round {r}: start {np.median(start):9.0f} (min {start.min():9.0f} max {start.max():9.0f}) | prologue wait med {np.median(pro):7.0f} max {pro.max():7.0f} | "
+          f"K loop med {np.median(loop):7.0f} min {loop.min():7.0f} max {loop.max():7.0f} | epilogue med {np.median(epi):6.0f} max {epi.max():6.0f}  [cycles]")
+tot_cycles = (s[:, rounds - 1, 0, 3] - s[:, 0, 0, 0])
+tot_real = (s[:, rounds - 1, 0, 4] - s[:, 0, 0, 4])
+print(f"kernel span per WG: med {np.median(tot_cycles):.0f} cycles")
+if rounds > 1:
+    dc = s[:, rounds - 1, 0, 3] - s[:, 0, 0, 3]
+    dr = s[:, rounds - 1, 0, 4] - s[:, 0, 0, 4]
+    print(f"in-kernel clock: {np.median(dc / dr) * 100:.0f} MHz")
+nk = a.k // 64
+print(f"ideal MFMA cycles per tile: {nk * 4 * 512}")
