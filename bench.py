@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--max-chains", type=int, default=1 << 16)
     ap.add_argument("--cpu-rows", type=int, default=192, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +101,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     d, hid, S, R, T = a.cols, a.hid, a.num_steps, a.resample, a.trials
+    folded = a.dtype == "bf16" and not a.no_fold
+    from diffputer_amd import _lib
+    _lib.check(_lib.load().dp_tune(b"fold_proj", 0 if a.no_fold else 1), "dp_tune")
     # random-init weights of the reference architecture (throughput is weight-independent), synthetic table shard
     sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(d, hid, seed=1, gain=1.0).items()}
     plan = SamplerPlan(sd, num_steps=S, n_resample=R, dtype=a.dtype, device=dev)
@@ -144,8 +148,12 @@ def main():
     rows_per_s = n_total * a.steps / dt
     nfe = nfe_per_chain(S, R)
     fl_row_eval = flops_per_row_eval(d, hid)
-    whole_tflops = rows_per_s * T * nfe * fl_row_eval / 1e12 / world      # per GPU
+    whole_tflops = rows_per_s * T * nfe * fl_row_eval / 1e12 / world      # per GPU, the reference's FLOP model
     peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+    # FLOPs the GEMM kernels actually execute per row-evaluation (padded widths; proj folded into mlp.0 in bf16)
+    H, K1 = hid, -(-d // 64) * 64
+    exec_row_eval = (2.0 * 2 * H * K1 if folded else 2.0 * H * K1 + 2.0 * 2 * H * H) + 2.0 * 2 * H * 2 * H + 2.0 * H * 2 * H + 2.0 * K1 * H
+    exec_tflops = rows_per_s * T * nfe * exec_row_eval / 1e12 / world
 
     result = {
         "metric": "imputed rows/sec (E-step, 50 steps x 10 trials)",
@@ -158,16 +166,20 @@ def main():
                    "chains_per_call": min(a.max_chains, a.rows * T), "parallelism": f"row-shard x{world}, all-gather of trial means"},
         "row_trials_per_s": rows_per_s * T, "denoiser_row_evals_per_s": rows_per_s * T * nfe,
         "whole_path": {"tflops_per_gpu": whole_tflops, "frac_of_mfma_peak": whole_tflops / peak,
-                       "flops_per_row": T * nfe * fl_row_eval},
+                       "flops_per_row": T * nfe * fl_row_eval,
+                       "note": "reference FLOP model 4DH+16H^2 per row-evaluation; executed_* counts the GEMMs as launched "
+                               "(proj folded into mlp.0: same function, fewer FLOPs)" if folded else "reference FLOP model",
+                       "executed_tflops_per_gpu": exec_tflops, "executed_frac_of_mfma_peak": exec_tflops / peak,
+                       "proj_folded_into_mlp0": folded},
     }
 
     if rank == 0 and not a.no_profile:
         ms, cnt = plan.profile_read()
         chains = min(a.max_chains, a.rows * T)
         Mp = -(-chains // 256) * 256
-        H = hid
-        K1 = N5 = -(-d // 64) * 64
-        layer_flops = [2.0 * Mp * H * K1, 2.0 * Mp * 2 * H * H, 2.0 * Mp * 2 * H * 2 * H, 2.0 * Mp * H * 2 * H, 2.0 * Mp * N5 * H]
+        N5 = K1
+        layer_flops = [2.0 * Mp * H * K1, 2.0 * Mp * 2 * H * (K1 if folded else H), 2.0 * Mp * 2 * H * 2 * H, 2.0 * Mp * H * 2 * H,
+                       2.0 * Mp * N5 * H]
         per = {}
         names = ["gemm_proj", "gemm_mlp0", "gemm_mlp2", "gemm_mlp4", "gemm_mlp6", "step_mid", "step_end", "step_final"]
         for i, nm in enumerate(names):
@@ -175,13 +187,14 @@ def main():
                 per[nm] = {"avg_ms": ms[i] / cnt[i], "samples": cnt[i]}
                 if i < 5:
                     per[nm]["tflops"] = layer_flops[i] / (ms[i] / cnt[i] * 1e-3) / 1e12
-        # dominant kernel: k_gemm_bf16<256,256,...,SiLU> = the mlp.0 / mlp.2 / mlp.4 launches (one of each per evaluation)
+        # dominant kernel: the SiLU / bf16-out GEMM = the (proj+)mlp.0, mlp.2, mlp.4 launches (one of each per evaluation);
+        # achieved = executed FLOPs of those launches / their in-situ duration
         if all(cnt[i] for i in (1, 2, 3)):
             avg_ms = sum(ms[i] / cnt[i] for i in (1, 2, 3)) / 3.0
             avg_flops = sum(layer_flops[i] for i in (1, 2, 3)) / 3.0
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                                  "kernel": "k_gemm_bf16<256,256,2,4,SiLU,bf16-out> (mlp.0, mlp.2, mlp.4)" if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
+                                  "kernel": ("k_gemm_bf16_pp<SiLU,bf16-out> (" + ("proj+mlp.0" if folded else "mlp.0") + ", mlp.2, mlp.4)") if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
                                   "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mp}
         # fused step kernel (after the 2nd evaluation): algorithmic bytes per cell = x_hat r/w 8 + d_cur 4 + F 4 + x_obs 4 + mask 1 + u 2
         if cnt[6]:

@@ -52,6 +52,11 @@ struct dp_plan {
     void* W[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // packed weights (bf16 or f32)
     float* B[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // biases (B[4] padded to N5; B[0] = proj.bias)
     float *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
+    // proj folded into mlp.0 (no activation separates them, model.py:126-128):
+    //   mlp.0(proj(u) + emb) = (W0 Wp) u + (W0 b_eff + b0)
+    void* W01 = nullptr;                 // packed [2 hid, K1] = W_mlp.0 W_proj
+    float* w0_f32 = nullptr;             // [2 hid, hid] float32 copy of mlp.0.weight (for the scratch levels' bias rows)
+    float* b01 = nullptr;                // [(n_levels + 2), 2 hid] = W0 b_eff[e] + b_mlp.0
     float *b_eff = nullptr;              // [(n_levels + 2), hid]; the last two rows are scratch for dp_denoise/dp_sample_step
     float *c_noise_dev = nullptr, *pe = nullptr, *hidden = nullptr;   // [(n_levels + 2)] / [.., hid] scratch
     // optional in-situ kernel timing (dp_plan_profile): event pairs around sampled evaluations
@@ -71,8 +76,10 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// tuning knob (dp_tune "gemm_variant"): 2 = ping-pong kernel for the wide layers (default), 1 = k_gemm_bf16 everywhere
+// tuning knobs (dp_tune): "gemm_variant" 2 = ping-pong kernel for the wide layers (default), 1 = k_gemm_bf16 everywhere;
+// "fold_proj" 1 = evaluate proj and mlp.0 as one Linear (default), 0 = as two GEMMs like the reference's module list
 static int g_gemm_variant = 2;
+static int g_fold_proj = 1;
 
 static int g_num_cus = 0;       // CUs of the current device: the persistent kernel runs one workgroup per CU
 
@@ -179,16 +186,27 @@ static Workspace carve(const dp_plan* p, int64_t M, void* base) {
     return w;
 }
 
-// ---- one denoiser evaluation F(u, level): five GEMMs with fused epilogues (model.py:121-128) ---------------------
+// proj folded into mlp.0: bf16 plans only -- the float32 path keeps the reference's operation order, so its parity
+// bound (1e-3 relative per step) is tested against the same sequence of roundings
+static bool folded(const dp_plan* p) { return g_fold_proj && p->dtype == DP_DTYPE_BF16; }
+
+// ---- one denoiser evaluation F(u, level): the Linear layers as GEMMs with fused epilogues (model.py:121-128) ------
+// `level` = row of the b_eff / b01 tables (0 .. n_levels-1 the schedule's levels, n_levels / n_levels+1 scratch).
 // `ev`: NULL, or 7 events of a profiling sample; [0..5] are recorded here, [6] by the caller after its step kernel.
-static int eval_F(const dp_plan* p, const Workspace& w, const float* b_eff_row, hipStream_t st, hipEvent_t* ev = nullptr) {
+static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t st, hipEvent_t* ev = nullptr) {
     const int H = p->hid, dt = p->dtype;
     int rc;
 #define DP_EV(i) do { if (ev) DP_HIP(hipEventRecord(ev[i], st)); } while (0)
     DP_EV(0);
-    if ((rc = gemm(dt, w.u, p->W[0], b_eff_row, w.actA, H, w.Mp, H, p->K1, 0, 0, st))) return rc;          // proj + emb (no act)
-    DP_EV(1);
-    if ((rc = gemm(dt, w.actA, p->W[1], p->B[1], w.actB, 2 * H, w.Mp, 2 * H, H, 1, 0, st))) return rc;      // mlp.0 + SiLU
+    if (folded(p)) {
+        // (W0 Wp) u + (W0 b_eff + b0), SiLU: proj + emb + mlp.0 + mlp.1 in one GEMM; slot 0 of the profile stays empty
+        DP_EV(1);
+        if ((rc = gemm(dt, w.u, p->W01, p->b01 + (size_t)level * 2 * H, w.actB, 2 * H, w.Mp, 2 * H, p->K1, 1, 0, st))) return rc;
+    } else {
+        if ((rc = gemm(dt, w.u, p->W[0], p->b_eff + (size_t)level * H, w.actA, H, w.Mp, H, p->K1, 0, 0, st))) return rc;   // proj + emb (no act)
+        DP_EV(1);
+        if ((rc = gemm(dt, w.actA, p->W[1], p->B[1], w.actB, 2 * H, w.Mp, 2 * H, H, 1, 0, st))) return rc;  // mlp.0 + SiLU
+    }
     DP_EV(2);
     if ((rc = gemm(dt, w.actB, p->W[2], p->B[2], w.actA, 2 * H, w.Mp, 2 * H, 2 * H, 1, 0, st))) return rc;  // mlp.2 + SiLU
     DP_EV(3);
@@ -221,7 +239,26 @@ static int compute_embedding(dp_plan* p, int first, int count, hipStream_t st) {
     hipLaunchKernelGGL(k_small_linear<false>, dim3(blocks), dim3(256), 0, st, p->hidden + (size_t)first * H, p->te_w2, p->te_b2, (const float*)p->B[0],
                        p->b_eff + (size_t)first * H, count, H, H);
     DP_LAUNCH_CHECK("k_small_linear");
+    // folded bias rows: b01[e] = W0 b_eff[e] + b_mlp.0
+    const int waves01 = count * 2 * H;
+    hipLaunchKernelGGL(k_small_linear<false>, dim3(ceil_div(waves01, 4)), dim3(256), 0, st, p->b_eff + (size_t)first * H, p->w0_f32, p->B[1],
+                       (const float*)nullptr, p->b01 + (size_t)first * 2 * H, count, 2 * H, H);
+    DP_LAUNCH_CHECK("k_small_linear(b01)");
     return DP_OK;
+}
+
+// W01[o, d] = sum_k W0[o, k] Wp[k, d]  (float32, k ascending), written zero-padded to [rows, ld] in the plan's dtype
+__global__ __launch_bounds__(256) void k_fold_proj(const float* __restrict__ W0, const float* __restrict__ Wp, void* dst, int rows, int H, int D,
+                                                   int ld, int to_bf16) {
+    const int64_t n = (int64_t)rows * ld;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx / ld), d = (int)(idx - (int64_t)o * ld);
+        float s = 0.f;
+        if (d < D)
+            for (int k = 0; k < H; ++k) s = fmaf(W0[(size_t)o * H + k], Wp[(size_t)k * D + d], s);
+        if (to_bf16) ((bf16_t*)dst)[idx] = f2bf(s);
+        else ((float*)dst)[idx] = s;
+    }
 }
 
 __global__ void k_set2(float* dst, float a, float b) { dst[0] = a; dst[1] = b; }
@@ -243,7 +280,9 @@ static void free_plan_events(dp_plan* p) {
 
 static void free_plan_buffers(dp_plan* p) {
     for (int i = 0; i < 5; ++i) { if (p->W[i]) (void)hipFree(p->W[i]); if (p->B[i]) (void)hipFree(p->B[i]); p->W[i] = nullptr; p->B[i] = nullptr; }
-    float** f[] = {&p->te_w0, &p->te_b0, &p->te_w2, &p->te_b2, &p->b_eff, &p->c_noise_dev, &p->pe, &p->hidden};
+    if (p->W01) (void)hipFree(p->W01);
+    p->W01 = nullptr;
+    float** f[] = {&p->te_w0, &p->te_b0, &p->te_w2, &p->te_b2, &p->b_eff, &p->c_noise_dev, &p->pe, &p->hidden, &p->w0_f32, &p->b01};
     for (auto q : f) { if (*q) (void)hipFree(*q); *q = nullptr; }
 }
 
@@ -341,6 +380,12 @@ int dp_plan_set_weights(dp_plan* p, const float* const w[7], const float* const 
     DP_HIP(hipMalloc((void**)&p->pe, (size_t)E * H * 4));
     DP_HIP(hipMalloc((void**)&p->hidden, (size_t)E * H * 4));
     DP_HIP(hipMalloc((void**)&p->c_noise_dev, (size_t)E * 4));
+    DP_HIP(hipMalloc(&p->W01, (size_t)2 * H * p->K1 * es));
+    DP_HIP(hipMalloc((void**)&p->w0_f32, (size_t)2 * H * H * 4));
+    DP_HIP(hipMalloc((void**)&p->b01, (size_t)E * 2 * H * 4));
+    DP_HIP(hipMemcpyAsync(p->w0_f32, w[1], (size_t)2 * H * H * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_fold_proj, dim3(grid_for((int64_t)2 * H * p->K1)), dim3(256), 0, st, w[1], w[0], p->W01, 2 * H, H, D, p->K1, bf);
+    DP_LAUNCH_CHECK("k_fold_proj");
     DP_HIP(hipMemcpyAsync(p->te_w0, w[5], (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
     DP_HIP(hipMemcpyAsync(p->te_w2, w[6], (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
     DP_HIP(hipMemcpyAsync(p->te_b0, b[5], (size_t)H * 4, hipMemcpyDeviceToDevice, st));
@@ -374,7 +419,7 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
     if (w.bytes > workspace_bytes)
         return fail(DP_EWORKSPACE, "workspace of %zu bytes is too small for %lld chains (need %zu)", workspace_bytes, (long long)M, w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    const int S = p->S, R = p->R, D = p->d_in, H = p->hid;
+    const int S = p->S, R = p->R, D = p->d_in;
     const int n_iter = R * (S - 1) + 1;
 
     StepCommon c;
@@ -399,14 +444,14 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
         const Level& l0 = p->lv[2 * i];
         const float h = p->t[i + 1] - p->th[i];
         hipEvent_t* ev = prof_slot(p, i < S - 1 ? 0 : 2);
-        if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i) * H, st, ev))) return rc;
+        if ((rc = eval_F(p, w, 2 * i, st, ev))) return rc;
         if (i < S - 1) {
             const Level& l1 = p->lv[2 * i + 1];
             hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
             DP_LAUNCH_CHECK("k_step_mid");
             if (ev) DP_HIP(hipEventRecord(ev[6], st));
             ev = prof_slot(p, 1);
-            if ((rc = eval_F(p, w, p->b_eff + (size_t)(2 * i + 1) * H, st, ev))) return rc;
+            if ((rc = eval_F(p, w, 2 * i + 1, st, ev))) return rc;
             const int add_re = j < R - 1;
             const int i_next = std::min((it + 1) / R, S - 1);
             hipLaunchKernelGGL(k_step_end, dim3(g), dim3(256), 0, st, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re,
@@ -446,7 +491,7 @@ int dp_plan_profile_read(dp_plan* p, double ms_sum[8], int count[8]) {
     for (int s = 0; s < p->prof_used; ++s) {
         hipEvent_t* ev = &p->prof_ev[(size_t)7 * s];
         DP_HIP(hipEventSynchronize(ev[6]));
-        for (int k = 0; k < 6; ++k) {
+        for (int k = folded(p) ? 1 : 0; k < 6; ++k) {           // folded: no separate proj launch between ev[0] and ev[1]
             float ms = 0.f;
             DP_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             const int slot = k < 5 ? k : 5 + p->prof_tag[s];        // 0..4 GEMM-1..5, 5 step_mid, 6 step_end, 7 step_final
@@ -481,7 +526,7 @@ int dp_denoise(dp_plan* p, const float* x, float sigma, float* D_out, float* F_o
     const int64_t cells = n * p->d_in;
     hipLaunchKernelGGL(k_scale_in, dim3(grid_for(cells)), dim3(256), 0, st, x, w.u, p->K1, (int)(p->dtype == DP_DTYPE_BF16), cells, p->d_in, k.c_in);
     DP_LAUNCH_CHECK("k_scale_in");
-    if ((rc = eval_F(p, w, p->b_eff + (size_t)p->n_levels * p->hid, st))) return rc;
+    if ((rc = eval_F(p, w, p->n_levels, st))) return rc;
     hipLaunchKernelGGL(k_precond_out, dim3(grid_for(cells)), dim3(256), 0, st, x, (const float*)w.F, p->N5, D_out, F_out, cells, p->d_in, k.c_skip, k.c_out);
     DP_LAUNCH_CHECK("k_precond_out");
     return DP_OK;
@@ -512,7 +557,7 @@ int dp_sample_step(dp_plan* p, int i, float t_cur, float t_next, const float* x_
     DP_HIP(hipMemsetAsync(w.u, 0, (size_t)w.Mp * p->K1 * p->esize(), st));
     hipLaunchKernelGGL(k_churn, dim3(g), dim3(256), 0, st, x_cur, eps, w.x_hat, w.u, p->K1, bf, cells, D, churn, k0.c_in, seed, row_offset, block);
     DP_LAUNCH_CHECK("k_churn");
-    if ((rc = eval_F(p, w, p->b_eff + (size_t)p->n_levels * p->hid, st))) return rc;
+    if ((rc = eval_F(p, w, p->n_levels, st))) return rc;
     if (heun) {
         StepCommon c;
         memset(&c, 0, sizeof c);
@@ -520,7 +565,7 @@ int dp_sample_step(dp_plan* p, int i, float t_cur, float t_next, const float* x_
         c.D = D; c.ldF = p->N5; c.ldu = p->K1; c.u_bf16 = bf;
         hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, k0.c_skip, k0.c_out, th, h, k1.c_in);
         DP_LAUNCH_CHECK("k_step_mid");
-        if ((rc = eval_F(p, w, p->b_eff + (size_t)(p->n_levels + 1) * p->hid, st))) return rc;
+        if ((rc = eval_F(p, w, p->n_levels + 1, st))) return rc;
         hipLaunchKernelGGL(k_heun_out, dim3(g), dim3(256), 0, st, (const float*)w.x_hat, (const float*)w.d_cur, (const float*)w.F, p->N5, x_next, cells, D,
                            k1.c_skip, k1.c_out, t_next, h, 1);
     } else {
@@ -572,6 +617,11 @@ int dp_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_variant")) {
         if (value < 1 || value > 2) return fail(DP_EINVAL, "gemm_variant must be 1 or 2");
         g_gemm_variant = value;
+        return DP_OK;
+    }
+    if (!strcmp(key, "fold_proj")) {
+        if (value < 0 || value > 1) return fail(DP_EINVAL, "fold_proj must be 0 or 1");
+        g_fold_proj = value;
         return DP_OK;
     }
     return fail(DP_EINVAL, "unknown tuning key '%s'", key);

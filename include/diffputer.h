@@ -135,8 +135,8 @@ int dp_plan_embedding(const dp_plan* plan, float* emb_out);
  * stride > 0 makes dp_impute bracket every stride-th denoiser evaluation with HIP events on the caller's stream
  * (at most 256 samples; stride = 0 switches it off).  dp_plan_profile_read waits for the recorded events and
  * returns summed milliseconds and sample counts per kernel slot: 0..4 = the five GEMM layers (proj, mlp.0, mlp.2,
- * mlp.4, mlp.6), 5 = step kernel after the first evaluation, 6 = step kernel after the second evaluation,
- * 7 = final-level step kernel.
+ * mlp.4, mlp.6; with "fold_proj" slot 0 stays empty and slot 1 is the folded proj+mlp.0 GEMM), 5 = step kernel after
+ * the first evaluation, 6 = step kernel after the second evaluation, 7 = final-level step kernel.
  */
 int dp_plan_profile(dp_plan* plan, int stride);
 int dp_plan_profile_read(dp_plan* plan, double ms_sum[8], int count[8]);
@@ -151,9 +151,12 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
               int64_t M, int N, int K, int act, int out_f32, void* stream);
 
 /*
- * Process-wide tuning knob for benchmarks and A/B tools (no counterpart in the reference; results are
- * identical for every setting).  Keys: "gemm_variant" = 2 ping-pong 256x256 kernel for the wide layers (default),
- * 1 = the simple double-buffered kernel everywhere.
+ * Process-wide tuning knobs for benchmarks and A/B tools (no counterpart in the reference).  Keys:
+ *   "gemm_variant"  2 = ping-pong 256x256 kernel for the wide layers (default), 1 = the simple double-buffered
+ *                   kernel everywhere; results are bit-identical.
+ *   "fold_proj"     1 (default) = in DP_DTYPE_BF16 plans proj and mlp.0 run as ONE Linear, (W0 Wp) u + (W0 (proj.bias + emb) + b0): no
+ *                   activation separates them (model.py:126-128), so this is the same function with one rounding
+ *                   of h0 fewer; 0 = two GEMMs as in the reference's module list.  Read at every evaluation.
  */
 int dp_tune(const char* key, int value);
 
