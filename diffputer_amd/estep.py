@@ -46,11 +46,12 @@ def impute_trials(plan: SamplerPlan, X, mask, num_trials: int, *, seed: int = 0,
     """Mean over `num_trials` trials of rec*mask + x_obs*(1-mask) for the rows given (main.py:160-188).
     X [n, D] float32 in the sampler's scale ((x-mean)/std/2, main.py:58); mask True = missing."""
     dev = plan.device
-    X = torch.as_tensor(X).to(dev, torch.float32)
-    m = torch.as_tensor(mask).to(dev)
+    # pandas-derived tables are often column-major: everything handed to the library must be row-major
+    X = torch.as_tensor(X).to(dev, torch.float32).contiguous()
+    m = torch.as_tensor(mask).to(dev).contiguous()
     x_obs = X if prefilled else ((1.0 - m.to(torch.float32)) * X)            # main.py:164
     m8 = m.to(torch.uint8).contiguous()
-    out = torch.zeros_like(x_obs)
+    out = torch.zeros(x_obs.shape, dtype=torch.float32, device=dev)
     n = x_obs.shape[0]
     if n == 0:
         return out

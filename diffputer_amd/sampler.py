@@ -152,6 +152,9 @@ class SamplerPlan:
         if out is None:
             out = torch.empty_like(x)
             accumulate = False
+        elif (not isinstance(out, torch.Tensor) or out.device != x.device or out.dtype != torch.float32
+              or tuple(out.shape) != tuple(x.shape) or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous (row-major) float32 tensor of x_obs's shape on the plan's device")
         nz = None
         if noise is not None:
             nz = torch.as_tensor(noise).to(self.device, torch.float32).contiguous()

@@ -1,0 +1,115 @@
+"""End-to-end parity on a TRAINED checkpoint (BASELINE.json north_star: final imputation MAE/RMSE on held-out
+masked cells within 1 % of the reference).
+
+Fixture tests/golden/e2e_california_H256.npz (tools/make_e2e_golden.py): the reference's own M-step trained a
+hid-256 denoiser on the california training table (MCAR 30 %, np.random.seed(0) masks), then its out-of-sample
+E-step (main.py:212-246) ran on the test table
+  * REPLAY: first 256 test rows, 1 trial, a seeded Gaussian stream replayed through torch.randn/randn_like
+            -> the GPU path fed the same stream must reproduce the output per cell;
+  * FREE:   all 2 044 rows, 5 trials, torch's generator under two seeds -> two MAE/RMSE pairs whose spread is
+            the noise floor for comparing against our counter-based Philox noise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from diffputer_amd import synth
+from diffputer_amd.evalmetrics import mae_rmse
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def e2e():
+    g = load_golden("e2e_california_H256")
+    sd = {k[4:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+    return g, sd
+
+
+def _plan(sd, g, dtype):
+    from diffputer_amd.sampler import SamplerPlan
+    return SamplerPlan(sd, num_steps=int(g["S"]), n_resample=int(g["R"]), dtype=dtype, device=DEV)
+
+
+def _replay_inputs(g):
+    n, d, S, R = int(g["replay_rows"]), int(g["d_in"]), int(g["S"]), int(g["R"])
+    noise = synth.reference_noise(int(g["nseed"]), synth.n_draws(S, R), (n, d))
+    assert float(np.asarray(noise, dtype=np.float64).sum()) == float(g["noise_checksum"])
+    X, m = g["X_test"][:n], g["mask_test"][:n]
+    return X, m, (X * (1.0 - m)).astype(np.float32), noise
+
+
+def test_replay_f32_per_cell(e2e):
+    """float32 path, identical noise: every cell of the final imputation within 1e-3 relative (floor 1e-2 = 2 % of the
+    data's std of 0.5)."""
+    g, sd = e2e
+    X, m, x_obs, noise = _replay_inputs(g)
+    p = _plan(sd, g, "f32")
+    out, _ = p.impute_sum(x_obs, m, 1, noise=noise)
+    out = out.cpu().numpy()
+    p.close()
+    ref = g["replay_out"]
+    err = np.abs(out - ref)
+    lim = 1e-3 * np.maximum(np.abs(ref), 1e-2)
+    assert np.all(err <= lim), (float(err.max()), float((err / lim).max()))
+    assert np.array_equal(out[~m], x_obs[~m])
+    mae, rmse = mae_rmse(out * 2, X * 2, m)
+    assert abs(mae - g["replay_mae_rmse"][0]) <= 1e-4 * g["replay_mae_rmse"][0]
+    assert abs(rmse - g["replay_mae_rmse"][1]) <= 1e-4 * g["replay_mae_rmse"][1]
+
+
+@pytest.mark.parametrize("fold", [1, 0], ids=["fold", "nofold"])
+def test_replay_bf16(e2e, fold):
+    """bf16 GEMM operands, identical noise.  The gate is the north star's: MAE and RMSE on the masked cells within 1 % of
+    the reference's on the same rows (measured on MI355X: +0.03 % / +0.03 %).  Per cell this briefly trained hid-256 net
+    is less contractive than SURVEY.md §0's hid-1024 one: measured mean |d| 1.2e-3, 2-3 % of cells above 5e-3, worst
+    cell 4.9e-2 (tools/e2e_diag2.py) -> bounds 3e-3 / 6 % / 2e-1."""
+    from diffputer_amd import _lib
+    g, sd = e2e
+    X, m, x_obs, noise = _replay_inputs(g)
+    lib = _lib.load()
+    _lib.check(lib.dp_tune(b"fold_proj", fold), "dp_tune")
+    try:
+        p = _plan(sd, g, "bf16")
+        out, _ = p.impute_sum(x_obs, m, 1, noise=noise)
+        out = out.cpu().numpy()
+        p.close()
+    finally:
+        _lib.check(lib.dp_tune(b"fold_proj", 1), "dp_tune")
+    ref = g["replay_out"]
+    mae, rmse = mae_rmse(out * 2, X * 2, m)
+    assert abs(mae - g["replay_mae_rmse"][0]) <= 1e-2 * g["replay_mae_rmse"][0], (mae, g["replay_mae_rmse"])
+    assert abs(rmse - g["replay_mae_rmse"][1]) <= 1e-2 * g["replay_mae_rmse"][1], (rmse, g["replay_mae_rmse"])
+    e = np.abs(out - ref)[m]
+    assert float(e.mean()) <= 3e-3 and float((e > 5e-3).mean()) <= 0.06 and float(e.max()) <= 2e-1, (e.mean(), (e > 5e-3).mean(), e.max())
+    assert np.array_equal(out[~m], x_obs[~m])
+
+
+def _robust(rec, X, m, clip=3.0):
+    """MAE, RMSE of the masked-cell errors clipped at `clip` (6 sigma_data in the x2 scale), and their median."""
+    err = np.minimum(np.abs((rec - X) * 2)[m], clip)
+    return np.asarray([err.mean(), np.sqrt((err ** 2).mean()), np.median(err)])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_free_run_error_distribution(e2e, dtype):
+    """Production mode (Philox noise, all 2 044 test rows, 5 trials, column-major input as pandas hands it over) against
+    the reference's two free runs.  With this briefly trained net a few chains DIVERGE in the reference itself (its two
+    seeds give RMSE 0.75 and 2.10, worst cell 13 vs 103; the HIP path shows the same rare cells), so plain MAE/RMSE of a
+    free run is a property of which chains blew up.  Compared instead: MAE and RMSE of errors clipped at 3 and the
+    median error -- each within 1 % of the reference's two-seed mean plus the reference's own two-seed spread."""
+    from diffputer_amd import estep
+    g, sd = e2e
+    X, m, T = g["X_test"], g["mask_test"], int(g["free_trials"])
+    p = _plan(sd, g, dtype)
+    rec = estep.impute_trials(p, np.asfortranarray(X), m, T, seed=2024).cpu().numpy()
+    p.close()
+    assert np.allclose(rec[~m], X[~m], rtol=1e-6, atol=0)                     # (5 x) / 5 rounds, as stack().mean(0) does
+    ours = _robust(rec, X, m)
+    ref = np.stack([_robust(g["free_out"][i], X, m) for i in range(2)])
+    mid, spread = ref.mean(0), np.abs(ref[0] - ref[1])
+    assert np.all(np.abs(ours - mid) <= 1e-2 * mid + spread), (ours, ref)
+    zf = g["zero_fill_mae_rmse"]
+    assert ours[0] < 0.8 * zf[0] and ours[1] < 0.8 * zf[1], "a trained denoiser must clearly beat zero-fill"

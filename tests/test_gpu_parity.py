@@ -301,6 +301,25 @@ def test_sharding_and_batching_invariance():
         p.close()
 
 
+def test_column_major_table_and_out_validation():
+    """A pandas-derived (column-major) table must give the result of its row-major copy; a strided `out` is refused."""
+    from diffputer_amd import estep
+    d, hid, S, R, n, T = 9, 64, 4, 3, 300, 2
+    sd = synth.make_weights(d, hid, 81, 1.5)
+    X, mask = synth.make_table(n, d, seed=82)
+    p = _plan(sd, S, R, "f32")
+    a = estep.impute_trials(p, X, mask, T, seed=9)
+    b = estep.impute_trials(p, np.asfortranarray(X), np.asfortranarray(mask), T, seed=9)
+    c = estep.impute_trials(p, torch.from_numpy(np.asfortranarray(X)).to(DEV), torch.from_numpy(mask).to(DEV), T, seed=9)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    with pytest.raises(ValueError):
+        p.impute_sum(x_obs, mask, 1, out=torch.zeros(d, n, device=DEV).t())
+    with pytest.raises(ValueError):
+        p.impute_sum(x_obs, mask, 1, out=torch.zeros(n, d, device=DEV, dtype=torch.float64))
+    p.close()
+
+
 def test_drop_in_api_matches_plan():
     """impute_mask / sample_step with the reference's signatures, fed a torch Model like main.py:170-180."""
     from diffputer_amd import diffusion_utils as du

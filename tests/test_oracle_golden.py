@@ -122,3 +122,21 @@ def test_estep_driver():
 
 def test_draw_count():
     assert synth.n_draws(50, 20) == 3924        # SURVEY.md §0 [probed]
+
+
+def test_trained_checkpoint_replay():
+    """The oracle against the reference's E-step on a TRAINED california checkpoint (tools/make_e2e_golden.py):
+    first 256 test rows, replayed noise; also pins the MAE/RMSE helper to the reference's get_eval numbers."""
+    from diffputer_amd.evalmetrics import mae_rmse
+    g = load_golden("e2e_california_H256")
+    sd = {k[4:].replace("__", "."): v for k, v in g.items() if k.startswith("sd__")}
+    n, d, S, R = int(g["replay_rows"]), int(g["d_in"]), int(g["S"]), int(g["R"])
+    noise = synth.reference_noise(int(g["nseed"]), synth.n_draws(S, R), (n, d))
+    assert float(np.asarray(noise, dtype=np.float64).sum()) == float(g["noise_checksum"])
+    X, m = g["X_test"][:n], g["mask_test"][:n]
+    x_obs = (X * (1.0 - m)).astype(np.float32)
+    out = orc.impute_mask(sd, x_obs, m, noise, S, R)
+    out = out * m + x_obs * (1.0 - m)                                   # main.py:232-233
+    close(out, g["replay_out"], atol=2e-5, rtol=1e-4)
+    mae, rmse = mae_rmse(out * 2, X * 2, m)
+    assert abs(mae - g["replay_mae_rmse"][0]) < 1e-5 and abs(rmse - g["replay_mae_rmse"][1]) < 1e-5
