@@ -9,12 +9,10 @@
 //   * 8 waves = 2 (m) x 4 (n), each owning 128 x 64 of the tile as 2 x 2 "quadrants" of 64 x 32;
 //   * a K-tile (64 deep) is cut into four 16-KiB HALF-TILES: A0/A1 = the first/second 64 rows of both wave rows,
 //     B0/B1 = the first/second 32 columns of all four wave columns; two K-tile buffers = 128 KiB of LDS;
-//   * a K-tile is four PHASES, one quadrant (16 MFMAs per wave) each:
-//        c0: read B0 (4 ds_read_b128) + A0 (8)   -> q(A0,B0)        c2: read A1 (8) -> q(A1,B1)
-//        c1: read B1 (4)                          -> q(A0,B1)        c3: (nothing)   -> q(A1,B0)   (B0 stays in registers)
-//     and every phase issues the LDS-DMA of ONE half-tile (2 x global_load_lds_dwordx4 per wave) 5-6 phases ahead
-//     of its first read:   c0: B1(t+1)   c1: A1(t+1)   c2: A0(t+2)   c3: B0(t+2)
-//   * phase = { ds_reads ; stage ; s_waitcnt vmcnt(8) ; s_barrier ; lgkmcnt(0) ; 16 MFMA ; s_barrier }.  The four
+//   * a K-tile is four PHASES, one quadrant (16 MFMAs per wave) each; B0 stays in registers for q(A1,B0) and B1 of
+//     the NEXT K-tile is read during that phase into the registers it does not use; every half-tile's LDS-DMA
+//     (2 x global_load_lds_dwordx4 per wave) is issued 5-6 phases ahead of its first read (table at PP_TILE);
+//   * phase = { ds_reads ; stage ; counted s_waitcnt vmcnt ; s_barrier ; lgkmcnt(0) ; 16 MFMA ; s_barrier }.  The four
 //     waves of wave row 1 run one barrier behind those of wave row 0, so on every SIMD one wave is in its MFMA
 //     segment while its partner reads LDS and issues DMA.
 //   * the workgroup is PERSISTENT (one per CU: it owns the whole 160 KiB of LDS) and walks output tiles
@@ -22,9 +20,9 @@
 //     of the current one, so the epilogue's SiLU, its stores and their drain hide under the next tile's first
 //     loads instead of leaving the chip idle while every CU stores at once.
 // Hazards (barrier instances b1, b2, ...; row 0 runs [R_P S_P W_P] b(2P+1) [M_P] b(2P+2), row 1 one barrier later):
-//   RAW  a half-tile read in phase Q was staged in phase <= Q-5; the vmcnt(8) of phase Q-1 (issued after that
-//        phase's stage) leaves only the four newest half-tiles in flight, and every wave has passed that wait
-//        before b(2Q), which precedes every read of phase Q.
+//   RAW  a half-tile read in phase Q was staged in phase <= Q-5; the counted vmcnt of phase Q-1 (issued after that
+//        phase's stage) leaves only newer half-tiles in flight, and every wave has passed that wait before b(2Q),
+//        which precedes every read of phase Q.
 //   WAR  a slot is re-staged >= 2 phases after its last ds_read: the lagging row's reads of phase P are complete
 //        (its lgkmcnt(0)) before it arrives at b(2P+3), and the leading row stages phase P+2 after b(2P+4).
 // The LDS image of a half-tile is the one of k_gemm_bf16: 8-row x 128-B pieces, 16-B chunk c of row r at c ^ (r&7)
@@ -44,9 +42,6 @@ __device__ __forceinline__ unsigned lds_u32(const void* p) { return (unsigned)(s
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_THREADS = 512;
 constexpr int PP_HALF = 16384;                                  // bytes of one half-tile
 constexpr int PP_LDS_BYTES = 8 * PP_HALF;                       // 2 K-tile buffers x {A0, A1, B0, B1}
-#ifndef PP_TAIL
-#define PP_TAIL 0
-#endif
 constexpr int PP_STAGE_WAVE = 4096;                             // epilogue staging per wave (32 rows x 128 B)
 constexpr int PP_LDS_TOTAL = PP_LDS_BYTES + 8 * PP_STAGE_WAVE;  // 160 KiB: the whole LDS of a CU
 
@@ -95,6 +90,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     // slot of (buffer b, operand o, half h) = ((b * 2 + o) * 2 + h) * 16 KiB
     auto stage_a = [&](int kt, int h) {
         char* dst = lds_piece + ((kt & 1) * 4 + h) * PP_HALF;
+#ifdef PP_DIAG_SAMEK
+        kt = kt & 1;                                             // diagnostic: every K-tile re-reads tiles 0/1 (L2 hits)
+#endif
+#ifdef PP_DIAG_NOSTAGE
+        if (kt >= 2) return;                                     // diagnostic: no DMA after the prologue (the waits pass at once)
+#endif
         const char* src = a_base + h * a_h + (size_t)kt * (PP_BK * 2);
         unsigned vo = a_voff;
         asm volatile("" : "+v"(vo));                             // keep base + offset un-hoisted: selects the saddr + voffset form
@@ -103,6 +104,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     };
     auto stage_b = [&](int kt, int h) {
         char* dst = lds_piece + ((kt & 1) * 4 + 2 + h) * PP_HALF;
+#ifdef PP_DIAG_SAMEK
+        kt = kt & 1;
+#endif
+#ifdef PP_DIAG_NOSTAGE
+        if (kt >= 2) return;
+#endif
         const char* src = w_base + h * w_h + (size_t)kt * (PP_BK * 2);
         unsigned vo = w_voff;
         asm volatile("" : "+v"(vo));
@@ -113,22 +120,28 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     auto prologue = [&](int m0, int n0) {
         a_base = (const char*)A + (size_t)m0 * K * 2;
         w_base = (const char*)W + (size_t)n0 * K * 2;
-        stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1); stage_a(1, 0); stage_b(1, 0);
+        stage_b(0, 1); stage_a(0, 0); stage_b(0, 0); stage_a(0, 1); stage_b(1, 1); stage_a(1, 0); stage_b(1, 0);
     };
 
     // ---- fragment reads: row (lane&15) of a 16-row tile, chunk ks*4 + lane/16, swizzled ----
     const int foff = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
-    const int a_rd = wm * 8192 + foff;                           // + i * 2048 (m-tile i of the half), ^ 64 for ks = 1
-    const int b_rd = 2 * PP_HALF + wn * 4096 + foff;             // + j * 2048 (n-tile j of the half)
+    // k-step 1 = chunk ^ 4 = byte offset ^ 64: kept as a second base so that tile offsets stay immediates
+    const int a_rd[2] = {wm * 8192 + foff, (wm * 8192 + foff) ^ 64};                      // + i * 2048 (m-tile i of the half)
+    const int b_rd[2] = {2 * PP_HALF + wn * 4096 + foff, (2 * PP_HALF + wn * 4096 + foff) ^ 64};   // + j * 2048 (n-tile j)
 
+#ifdef PP_DIAG_NOREAD                                            /* timing-only diagnostic: operands stay what they were */
+#define PP_READ_A(buf, h)                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[ks][i]))
+#define PP_READ_B(dst, buf, h)                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(dst[ks][j]))
+#else
 #define PP_READ_A(buf, h)                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)              \
-        af[ks][i] = *(const bf16x8*)((buf) + (h) * PP_HALF + ((a_rd + i * 2048) ^ (ks * 64)))
+        af[ks][i] = *(const bf16x8*)((buf) + (h) * PP_HALF + a_rd[ks] + i * 2048)
 #define PP_READ_B(dst, buf, h)                                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
-        dst[ks][j] = *(const bf16x8*)((buf) + (h) * PP_HALF + ((b_rd + j * 2048) ^ (ks * 64)))
-    // The closing barrier sits PP_TAIL MFMAs before the end of the cluster: barriers order LDS reads and DMA issue,
-    // not the register-only MFMAs, and the partner wave's hand-off latency then hides under this wave's last MFMAs.
+        dst[ks][j] = *(const bf16x8*)((buf) + (h) * PP_HALF + b_rd[ks] + j * 2048)
+#endif
 #define PP_MFMA(ha, hb, bfr)                                                                                    \
     do {                                                                                                        \
         __builtin_amdgcn_s_barrier();                                                                           \
@@ -136,32 +149,33 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                          \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                     \
-                if (ks * 8 + i * 2 + j == 16 - PP_TAIL) {                                                       \
-                    __builtin_amdgcn_sched_barrier(0);                                                          \
-                    __builtin_amdgcn_s_barrier();                                                               \
-                    __builtin_amdgcn_sched_barrier(0);                                                          \
-                }                                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
                 acc[ha][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[ha][i][hb][j], 0, 0, 0); \
-            }                                                                                                   \
         __builtin_amdgcn_s_setprio(0);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (PP_TAIL == 0) __builtin_amdgcn_s_barrier();                                                         \
+        __builtin_amdgcn_s_barrier();                                                                           \
     } while (0)
-    // One K-tile.  ST1: tile kt+1 exists (stage B1, A1 of it); ST2: tile kt+2 exists (stage A0, B0 of it).
-    // WAIT(c): the vmcnt after the stage of phase c.
+    // One K-tile (DMA issue kept out of the phase with the 12 fragment reads; B1 read one phase early into
+    // the registers q(A1,B0) does not use):
+    //   phase   ds_read_b128                 LDS-DMA (half-tiles)         MFMA quadrant    vmcnt after the stage
+    //   c0      B0(t) 4 + A0(t) 8            -                            q(A0,B0)         -
+    //   c1      -                            A1(t+1), B1(t+2)             q(A0,B1)         10  (A1(t) landed)
+    //   c2      A1(t) 8                      A0(t+2)                      q(A1,B1)         10  (B1(t+1) landed)
+    //   c3      B1(t+1) 4                    B0(t+2)                      q(A1,B0)          8  (A0(t+1), B0(t+1) landed)
+    // Issue order of the DMA stream: ... A1(t+1) B1(t+2) A0(t+2) B0(t+2) A1(t+2) B1(t+3) ...; every half-tile is read
+    // >= 5 phases after its DMA and re-staged >= 2 phases after its last read (A0, B0: +2/+3; A1: +3; B1: +2).
+    // ST1: tile kt+1 exists; ST2: tile kt+2 exists.  WAIT(c): the vmcnt after the stage of phase c.
 #define PP_TILE(kt, ST1, ST2, WAIT)                                                                             \
     do {                                                                                                        \
         const char* buf = smem + ((kt) & 1) * 4 * PP_HALF;                                                      \
+        const char* nbuf = smem + (((kt) + 1) & 1) * 4 * PP_HALF;                                               \
         /* c0 */                                                                                                \
         PP_READ_B(bf0, buf, 0);                                                                                 \
         PP_READ_A(buf, 0);                                                                                      \
-        if (ST1) stage_b((kt) + 1, 1);                                                                          \
-        WAIT(0);                                                                                                \
         PP_MFMA(0, 0, bf0);                                                                                     \
         /* c1 */                                                                                                \
-        PP_READ_B(bf1, buf, 1);                                                                                 \
         if (ST1) stage_a((kt) + 1, 1);                                                                          \
+        if (ST2) stage_b((kt) + 2, 1);                                                                          \
         WAIT(1);                                                                                                \
         PP_MFMA(0, 1, bf1);                                                                                     \
         /* c2 */                                                                                                \
@@ -170,16 +184,17 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         WAIT(2);                                                                                                \
         PP_MFMA(1, 1, bf1);                                                                                     \
         /* c3 */                                                                                                \
+        if (ST1) PP_READ_B(bf1, nbuf, 1);                                                                       \
         if (ST2) stage_b((kt) + 2, 0);                                                                          \
         WAIT(3);                                                                                                \
         PP_MFMA(1, 0, bf0);                                                                                     \
     } while (0)
-    // steady state: leave the four newest half-tiles in flight.  During K-tile 0 of a tile whose prologue was issued
-    // ahead of the previous epilogue, that epilogue's NST stores sit behind the prologue DMA in the queue.
-#define PP_WAIT_MAIN(c) DP_VMCNT(8)
-#define PP_WAIT_T0(c) DP_VMCNT_N(8 + NST)                                                        /* K-tile 0 behind an epilogue */
-#define PP_WAIT_T2(c) do { if ((c) < 3) { DP_VMCNT(8); } else { DP_VMCNT(4); } } while (0)       /* tile nk-2 */
-#define PP_WAIT_T1(c) do { if ((c) == 0) { DP_VMCNT(2); } else { DP_VMCNT(0); } } while (0)      /* tile nk-1 */
+    // During K-tile 0 of a tile whose prologue was issued ahead of the previous epilogue, that epilogue's NST stores sit
+    // behind the prologue DMA in the in-order vmcnt queue.
+#define PP_WAIT_MAIN(c) do { if ((c) == 3) { DP_VMCNT(8); } else { DP_VMCNT(10); } } while (0)
+#define PP_WAIT_T0(c) do { if ((c) == 3) { DP_VMCNT_N(8 + NST); } else { DP_VMCNT_N(10 + NST); } } while (0)
+#define PP_WAIT_T2(c) do { if ((c) == 1) { DP_VMCNT(8); } else if ((c) == 2) { DP_VMCNT(6); } else { DP_VMCNT(2); } } while (0)  /* tile nk-2 */
+#define PP_WAIT_T1(c) DP_VMCNT(0)                                                                                /* tile nk-1 */
 
     // tile coordinates live in SGPRs (integer division runs on the VALU: read the result back)
     auto tile_m0 = [&](int tile) { return __builtin_amdgcn_readfirstlane((tile / nbn) * PP_BM); };
@@ -205,11 +220,21 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bf16x8 af[2][4], bf0[2][2], bf1[2][2];                   // [ks][tile]
+#ifdef PP_DIAG_NOREAD
+        for (int ks = 0; ks < 2; ++ks) {
+            for (int i = 0; i < 4; ++i) af[ks][i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+            for (int j = 0; j < 2; ++j) { bf0[ks][j] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8}; bf1[ks][j] = (bf16x8){8, 7, 6, 5, 4, 3, 2, 1}; }
+        }
+#endif
 
         // A0(0), B0(0) have landed (this wave's pieces): all but the 4 newer half-tiles (and the epilogue's stores)
         if (first) { DP_VMCNT(8); } else { DP_VMCNT_N(8 + NST); }
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();               // wave row 1 runs one barrier behind
+        PP_READ_B(bf1, smem, 1);                                 // "phase -1": B1(0), a phase of its own so that its slot
+        __builtin_amdgcn_s_barrier();                            // may be re-staged in phase 1 like every later B1
+        DP_LGKMCNT0();
+        __builtin_amdgcn_s_barrier();
         PP_STAMP(1);
 
         if (first) PP_TILE(0, true, true, PP_WAIT_MAIN);
@@ -217,9 +242,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         int kt = 1;
 #pragma clang loop unroll(disable)
         for (; kt < nk - 2; ++kt) PP_TILE(kt, true, true, PP_WAIT_MAIN);
-        PP_TILE(kt, true, false, PP_WAIT_T2);                    // c3: A0, B0 of tile nk-1 must land -> 2 newer half-tiles
+        PP_TILE(kt, true, false, PP_WAIT_T2);                    // tile nk-2: only the stages of tile nk-1 are left
         ++kt;
-        PP_TILE(kt, false, false, PP_WAIT_T1);                   // c0: B1(nk-1) must land -> 1 newer; c1: A1(nk-1)
+        PP_TILE(kt, false, false, PP_WAIT_T1);                   // tile nk-1: nothing left to stage
         if (wm == 0) __builtin_amdgcn_s_barrier();               // balance wave row 1's extra barrier: LDS is quiescent
         PP_STAMP(2);
 

@@ -21,7 +21,8 @@ ap.add_argument("--n", type=int, default=2048)
 ap.add_argument("--k", type=int, default=2048)
 ap.add_argument("--iters", type=int, default=20)
 a = ap.parse_args()
-lib = C.CDLL(os.path.join(REPO, "tools", "diag", "libdiffputer_hip_stamp.so"))
+ap2 = os.environ.get("DP_DIAG_LIB", os.path.join(REPO, "tools", "diag", "libdiffputer_hip_stamp.so"))
+lib = C.CDLL(ap2)
 lib.dp_last_error.restype = C.c_char_p
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
