@@ -70,6 +70,22 @@ def cpu_baseline(d, hid, S, R, T, rows, budget_note):
             "row_trials_per_s": row_trials_per_s}
 
 
+def pmc_traffic(kernel: str, rows_per_launch: int):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE passes of their own, corrected as MI355X_MICROARCH.md §HBM prescribes; tools/pmc_summary.py).  Counters
+    cannot be read inside a timed run, so this is the last measurement on file, valid for the same rows per launch."""
+    path = os.path.join(REPO, "PMC_TRAFFIC.json")     # = profiles/r1_v3_pmc_summary.json (profiles/ does not travel to the GPU box)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d[kernel]
+        if int(d.get("_rows_per_launch", 0)) != int(rows_per_launch):
+            return None, f"PMC_TRAFFIC.json is for {d.get('_rows_per_launch')} rows per launch"
+        return e["traffic_bytes"], "PMC_TRAFFIC.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, L2 fabric side (Infinity-Cache hits included)"
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC summary on file"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +209,9 @@ def main():
             avg_ms = sum(ms[i] / cnt[i] for i in (1, 2, 3)) / 3.0
             avg_flops = sum(layer_flops[i] for i in (1, 2, 3)) / 3.0
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, false>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mp)
+            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                                  "traffic_source": traffic_src,
                                   "kernel": ("k_gemm_bf16_pp<SiLU,bf16-out> (" + ("proj+mlp.0" if folded else "mlp.0") + ", mlp.2, mlp.4)") if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
                                   "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mp}
         # fused step kernel (after the 2nd evaluation): algorithmic bytes per cell = x_hat r/w 8 + d_cur 4 + F 4 + x_obs 4 + mask 1 + u 2
