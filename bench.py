@@ -78,7 +78,7 @@ def pmc_traffic(kernel: str, rows_per_launch: int):
     try:
         with open(path) as f:
             d = json.load(f)
-        e = d[kernel]
+        e = d.get(kernel) or d[kernel.replace("<true, 0>", "<true, false>")]
         if int(d.get("_rows_per_launch", 0)) != int(rows_per_launch):
             return None, f"PMC_TRAFFIC.json is for {d.get('_rows_per_launch')} rows per launch"
         return e["traffic_bytes"], "PMC_TRAFFIC.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, L2 fabric side (Infinity-Cache hits included)"
@@ -209,7 +209,7 @@ def main():
             avg_ms = sum(ms[i] / cnt[i] for i in (1, 2, 3)) / 3.0
             avg_flops = sum(layer_flops[i] for i in (1, 2, 3)) / 3.0
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, false>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mp)
+            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mp)
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                   "traffic_source": traffic_src,
                                   "kernel": ("k_gemm_bf16_pp<SiLU,bf16-out> (" + ("proj+mlp.0" if folded else "mlp.0") + ", mlp.2, mlp.4)") if a.dtype == "bf16" else "k_gemm_f32<SiLU>",

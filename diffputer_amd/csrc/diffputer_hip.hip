@@ -80,11 +80,12 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
 // "fold_proj" 1 = evaluate proj and mlp.0 as one Linear (default), 0 = as two GEMMs like the reference's module list
 static int g_gemm_variant = 2;
 static int g_fold_proj = 1;
+static int g_fuse_mid = 1;        // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 
 static int g_num_cus = 0;       // CUs of the current device: the persistent kernel runs one workgroup per CU
 
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
-                          int act, int out_f32, hipStream_t st) {
+                          int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr) {
     const int nbn = N / PP_BN;
     const int64_t nwg64 = (M / PP_BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
@@ -96,20 +97,24 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
         DP_HIP(hipGetDeviceProperties(&prop, dev));
         g_num_cus = prop.multiProcessorCount;
     }
-#define DP_GO(ACT, OF)                                                                                              \
+    const MidStep ms = mid ? *mid : MidStep{};
+#define DP_GO(ACT, EP)                                                                                              \
     do {                                                                                                            \
-        auto kern = k_gemm_bf16_pp<ACT, OF>;                                                                        \
+        auto kern = k_gemm_bf16_pp<ACT, EP>;                                                                        \
         static bool attr_done = false;                                                                              \
         if (!attr_done) {                                                                                           \
             DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL)); \
             attr_done = true;                                                                                       \
         }                                                                                                           \
-        hipLaunchKernelGGL(kern, dim3(std::min(nwg, g_num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg); \
+        hipLaunchKernelGGL(kern, dim3(std::min(nwg, g_num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms); \
     } while (0)
-    if (act && !out_f32) DP_GO(true, false);
-    else if (!act && !out_f32) DP_GO(false, false);
-    else if (!act && out_f32) DP_GO(false, true);
-    else DP_GO(true, true);
+    if (mid) {
+        if (act || N != 256) return fail(DP_EINVAL, "the fused mid-step epilogue needs N = 256 and no activation");
+        DP_GO(false, EPI_MID);
+    } else if (act && !out_f32) DP_GO(true, EPI_BF16);
+    else if (!act && !out_f32) DP_GO(false, EPI_BF16);
+    else if (!act && out_f32) DP_GO(false, EPI_F32);
+    else DP_GO(true, EPI_F32);
 #undef DP_GO
     DP_LAUNCH_CHECK("k_gemm_bf16_pp");
     return DP_OK;
@@ -189,11 +194,15 @@ static Workspace carve(const dp_plan* p, int64_t M, void* base) {
 // proj folded into mlp.0: bf16 plans only -- the float32 path keeps the reference's operation order, so its parity
 // bound (1e-3 relative per step) is tested against the same sequence of roundings
 static bool folded(const dp_plan* p) { return g_fold_proj && p->dtype == DP_DTYPE_BF16; }
+// the step after a Heun iteration's first evaluation runs in mlp.6's epilogue when that GEMM's tile spans the whole row
+static bool mid_fused(const dp_plan* p) {
+    return g_fuse_mid && g_gemm_variant == 2 && p->dtype == DP_DTYPE_BF16 && p->d_in == 256 && p->hid >= 3 * PP_BK;
+}
 
 // ---- one denoiser evaluation F(u, level): the Linear layers as GEMMs with fused epilogues (model.py:121-128) ------
 // `level` = row of the b_eff / b01 tables (0 .. n_levels-1 the schedule's levels, n_levels / n_levels+1 scratch).
 // `ev`: NULL, or 7 events of a profiling sample; [0..5] are recorded here, [6] by the caller after its step kernel.
-static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t st, hipEvent_t* ev = nullptr) {
+static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t st, hipEvent_t* ev = nullptr, const MidStep* mid = nullptr) {
     const int H = p->hid, dt = p->dtype;
     int rc;
 #define DP_EV(i) do { if (ev) DP_HIP(hipEventRecord(ev[i], st)); } while (0)
@@ -212,7 +221,9 @@ static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t s
     DP_EV(3);
     if ((rc = gemm(dt, w.actA, p->W[3], p->B[3], w.actB, H, w.Mp, H, 2 * H, 1, 0, st))) return rc;          // mlp.4 + SiLU
     DP_EV(4);
-    if ((rc = gemm(dt, w.actB, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;         // mlp.6 -> f32
+    if (mid) {                                                                                              // mlp.6 + the mid step
+        if ((rc = launch_bf16_pp((const bf16_t*)w.actB, (const bf16_t*)p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st, mid))) return rc;
+    } else if ((rc = gemm(dt, w.actB, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;   // mlp.6 -> f32
     DP_EV(5);
 #undef DP_EV
     return DP_OK;
@@ -434,9 +445,17 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
 
     // pad rows / pad columns of u stay zero for the whole call; the step kernels only write [0,M) x [0,D)
     DP_HIP(hipMemsetAsync(w.u, 0, (size_t)w.Mp * p->K1 * p->esize(), st));
-    const int g = grid_for(c.n_cells);
-    hipLaunchKernelGGL(k_step_init, dim3(g), dim3(256), 0, st, c, p->t[0], p->churn[0], p->lv[0].c.c_in);
-    DP_LAUNCH_CHECK("k_step_init");
+    // 4 cells per thread when every row of every table starts 16-byte aligned (mask: 4-byte)
+    const bool vec = D % 4 == 0 && ((uintptr_t)x_obs & 15) == 0 && ((uintptr_t)mask & 3) == 0 && ((uintptr_t)out & 15) == 0 &&
+                     (!trace || ((uintptr_t)trace & 15) == 0);
+    const int g = grid_for(c.n_cells / (vec ? 4 : 1));
+#define DP_STEP(K, G, ...)                                                                       \
+    do {                                                                                         \
+        if (vec) hipLaunchKernelGGL(K<4>, dim3(G), dim3(256), 0, st, __VA_ARGS__);               \
+        else hipLaunchKernelGGL(K<1>, dim3(G), dim3(256), 0, st, __VA_ARGS__);                   \
+        DP_LAUNCH_CHECK(#K);                                                                     \
+    } while (0)
+    DP_STEP(k_step_init, g, c, p->t[0], p->churn[0], p->lv[0].c.c_in);
 
     for (int it = 0; it < n_iter; ++it) {
         const int i = std::min(it / R, S - 1);
@@ -444,27 +463,31 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
         const Level& l0 = p->lv[2 * i];
         const float h = p->t[i + 1] - p->th[i];
         hipEvent_t* ev = prof_slot(p, i < S - 1 ? 0 : 2);
-        if ((rc = eval_F(p, w, 2 * i, st, ev))) return rc;
+        MidStep ms;
+        const bool fuse = i < S - 1 && mid_fused(p);
+        if (fuse) {
+            ms.x_hat = w.x_hat; ms.d_cur = w.d_cur; ms.u = (bf16_t*)w.u; ms.m_valid = M; ms.ldu = p->K1;
+            ms.c_skip = l0.c.c_skip; ms.c_out = l0.c.c_out; ms.t_hat = p->th[i]; ms.h = h; ms.c_in_next = p->lv[2 * i + 1].c.c_in;
+        }
+        if ((rc = eval_F(p, w, 2 * i, st, ev, fuse ? &ms : nullptr))) return rc;
         if (i < S - 1) {
             const Level& l1 = p->lv[2 * i + 1];
-            hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
-            DP_LAUNCH_CHECK("k_step_mid");
+            if (!fuse) DP_STEP(k_step_mid, g, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
             if (ev) DP_HIP(hipEventRecord(ev[6], st));
             ev = prof_slot(p, 1);
             if ((rc = eval_F(p, w, 2 * i + 1, st, ev))) return rc;
             const int add_re = j < R - 1;
             const int i_next = std::min((it + 1) / R, S - 1);
-            hipLaunchKernelGGL(k_step_end, dim3(g), dim3(256), 0, st, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re,
-                               p->churn[i_next], p->lv[2 * i_next].c.c_in);
-            DP_LAUNCH_CHECK("k_step_end");
+            DP_STEP(k_step_end, g, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re, p->churn[i_next],
+                    p->lv[2 * i_next].c.c_in);
             if (ev) DP_HIP(hipEventRecord(ev[6], st));
         } else {
-            hipLaunchKernelGGL(k_step_final, dim3(grid_for(n_rows * D)), dim3(256), 0, st, c, it, l0.c.c_skip, l0.c.c_out, p->th[i], h, out,
-                               (flags & DP_ACCUMULATE) ? 1 : 0);
-            DP_LAUNCH_CHECK("k_step_final");
+            DP_STEP(k_step_final, grid_for(n_rows * D / (vec ? 4 : 1)), c, it, l0.c.c_skip, l0.c.c_out, p->th[i], h, out,
+                    (flags & DP_ACCUMULATE) ? 1 : 0);
             if (ev) DP_HIP(hipEventRecord(ev[6], st));
         }
     }
+#undef DP_STEP
     return DP_OK;
 }
 
@@ -494,6 +517,7 @@ int dp_plan_profile_read(dp_plan* p, double ms_sum[8], int count[8]) {
         for (int k = folded(p) ? 1 : 0; k < 6; ++k) {           // folded: no separate proj launch between ev[0] and ev[1]
             float ms = 0.f;
             DP_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            if (k == 5 && p->prof_tag[s] == 0 && mid_fused(p)) continue;   // the mid step ran inside mlp.6: no launch to time
             const int slot = k < 5 ? k : 5 + p->prof_tag[s];        // 0..4 GEMM-1..5, 5 step_mid, 6 step_end, 7 step_final
             ms_sum[slot] += ms;
             count[slot] += 1;
@@ -563,7 +587,7 @@ int dp_sample_step(dp_plan* p, int i, float t_cur, float t_next, const float* x_
         memset(&c, 0, sizeof c);
         c.x_hat = w.x_hat; c.d_cur = w.d_cur; c.F = w.F; c.u = w.u; c.n_cells = cells; c.n_rows = n;
         c.D = D; c.ldF = p->N5; c.ldu = p->K1; c.u_bf16 = bf;
-        hipLaunchKernelGGL(k_step_mid, dim3(g), dim3(256), 0, st, c, k0.c_skip, k0.c_out, th, h, k1.c_in);
+        hipLaunchKernelGGL(k_step_mid<1>, dim3(g), dim3(256), 0, st, c, k0.c_skip, k0.c_out, th, h, k1.c_in);
         DP_LAUNCH_CHECK("k_step_mid");
         if ((rc = eval_F(p, w, p->n_levels + 1, st))) return rc;
         hipLaunchKernelGGL(k_heun_out, dim3(g), dim3(256), 0, st, (const float*)w.x_hat, (const float*)w.d_cur, (const float*)w.F, p->N5, x_next, cells, D,
@@ -617,6 +641,11 @@ int dp_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_variant")) {
         if (value < 1 || value > 2) return fail(DP_EINVAL, "gemm_variant must be 1 or 2");
         g_gemm_variant = value;
+        return DP_OK;
+    }
+    if (!strcmp(key, "fuse_mid")) {
+        if (value < 0 || value > 1) return fail(DP_EINVAL, "fuse_mid must be 0 or 1");
+        g_fuse_mid = value;
         return DP_OK;
     }
     if (!strcmp(key, "fold_proj")) {

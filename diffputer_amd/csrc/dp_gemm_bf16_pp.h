@@ -29,6 +29,7 @@
 // (swizzle on the DMA's per-lane SOURCE address and on the ds_read; conflict-free ds_read_b128).
 #pragma once
 #include "dp_gemm_bf16.h"
+#include "dp_step.h"
 
 namespace dp {
 
@@ -59,10 +60,21 @@ __device__ unsigned long long* g_pp_stamp_buf = nullptr;        // [gridDim][16 
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-template <bool ACT, bool OUT_F32>
+// EPI: what the epilogue does with act(acc + bias)
+//   EPI_BF16  store as bf16 (whole 128-B rows through the LDS transposer)
+//   EPI_F32   store as float32
+//   EPI_MID   N = 256 = the table's width: the value is the raw network output F of the FIRST evaluation of a Heun
+//             iteration; apply k_step_mid's arithmetic in place (reads x_hat, writes d_cur and the next evaluation's
+//             input u) instead of storing F.  Its epilogue waits on ordinary loads, so the next tile's prologue is
+//             issued after it, not before.
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_MID = 2 };
+
+template <bool ACT, int EPI>
 __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
-                                                              int ldo, int K, int nbn, int nwg) {
+                                                              int ldo, int K, int nbn, int nwg, MidStep ms) {
+    constexpr bool OUT_F32 = EPI == EPI_F32;
+    constexpr bool PREFETCH = EPI != EPI_MID;                   // next tile's prologue DMA ahead of this tile's epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // vector-memory instructions one wave's epilogue issues (they sit between the next tile's prologue DMA and its
     // phase DMA in the in-order vmcnt queue)
@@ -271,10 +283,37 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         if (more) {
             m0 = tile_m0(tile);
             n0 = tile_n0(tile);
-            prologue(m0, n0);
+            if (PREFETCH) prologue(m0, n0);
         }
 
-        if (OUT_F32) {
+        if (EPI == EPI_MID) {
+            const int64_t row0 = om + (elane & 15);
+            const int col0 = on + (elane >> 4) * 4;
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = row0 + ha * 64 + i * 16;
+                    if (m < ms.m_valid) {
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int col = col0 + hb * 32 + j * 16;
+                                const f32x4 c = acc[ha][i][hb][j];
+                                const float4 xh = *(const float4*)(ms.x_hat + m * 256 + col);
+                                float4 d, u;
+                                mid_step_cell(xh.x, c[0] + bv[hb][j].x, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.x, u.x);
+                                mid_step_cell(xh.y, c[1] + bv[hb][j].y, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.y, u.y);
+                                mid_step_cell(xh.z, c[2] + bv[hb][j].z, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.z, u.z);
+                                mid_step_cell(xh.w, c[3] + bv[hb][j].w, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.w, u.w);
+                                *(float4*)(ms.d_cur + m * 256 + col) = d;
+                                *(uint2*)(ms.u + m * ms.ldu + col) = make_uint2(pack_bf16x2(u.x, u.y), pack_bf16x2(u.z, u.w));
+                            }
+                    }
+                }
+            if (more) prologue(m0, n0);
+        } else if (OUT_F32) {
             float* const orow = (float*)out + (size_t)(om + (elane & 15)) * ldo + on + (elane >> 4) * 4;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
@@ -341,7 +380,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         ++round;
 #endif
         if (!more) break;
-        first = false;
+        first = !PREFETCH;                                       // without the prefetch no stores sit behind the prologue DMA
     }
 
 #undef PP_WAIT_MAIN

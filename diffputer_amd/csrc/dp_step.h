@@ -35,10 +35,15 @@ struct StepCommon {
     int D, ldF, ldu, u_bf16, trial_offset, num_trials;
 };
 
-__device__ __forceinline__ void store_u(const StepCommon& c, int64_t m, int col, float v) {
-    if (c.u_bf16) ((bf16_t*)c.u)[m * c.ldu + col] = f2bf(v);
-    else ((float*)c.u)[m * c.ldu + col] = v;
-}
+// What the mlp.6 GEMM needs to finish the first half of a Heun iteration in its epilogue (EPI_MID): D = 256 columns
+struct MidStep {
+    const float* x_hat;    // [m_valid, 256]
+    float* d_cur;          // [m_valid, 256]
+    bf16_t* u;             // [Mp, ldu]
+    int64_t m_valid;       // chains; GEMM rows beyond it are padding
+    int ldu;
+    float c_skip, c_out, t_hat, h, c_in_next;
+};
 
 struct Cell { int64_t m, row; int col, tl; };
 __device__ __forceinline__ Cell cell_of(const StepCommon& c, int64_t e) {
@@ -56,100 +61,170 @@ __device__ __forceinline__ float draw(const StepCommon& c, const Cell& k, int64_
 
 #pragma clang fp contract(off)
 
+// The four sampler kernels are templated on V = cells per thread (consecutive columns of one row): V = 4 when D % 4 == 0
+// and the caller's tables are 16-byte aligned (16-byte loads and stores, a quarter of the memory instructions), else 1.
+// The per-cell arithmetic is the same sequence of float32 operations for either V.
+template <int V> struct VecF { float v[V]; };
+template <int V> __device__ __forceinline__ VecF<V> ldf(const float* p) {
+    VecF<V> r;
+    if (V == 4) { const float4 t = *(const float4*)p; r.v[0] = t.x; r.v[1 % V] = t.y; r.v[2 % V] = t.z; r.v[3 % V] = t.w; }
+    else r.v[0] = *p;
+    return r;
+}
+template <int V> __device__ __forceinline__ void stf(float* p, const VecF<V>& r) {
+    if (V == 4) *(float4*)p = make_float4(r.v[0], r.v[1 % V], r.v[2 % V], r.v[3 % V]);
+    else *p = r.v[0];
+}
+template <int V> __device__ __forceinline__ void store_u(const StepCommon& c, int64_t m, int col, const VecF<V>& r) {
+    if (c.u_bf16) {
+        bf16_t* p = (bf16_t*)c.u + m * c.ldu + col;
+        if (V == 4) *(uint2*)p = make_uint2(pack_bf16x2(r.v[0], r.v[1 % V]), pack_bf16x2(r.v[2 % V], r.v[3 % V]));
+        else *p = f2bf(r.v[0]);
+    } else {
+        stf<V>((float*)c.u + m * c.ldu + col, r);
+    }
+}
+template <int V> __device__ __forceinline__ VecF<V> ldmask(const uint8_t* p) {
+    VecF<V> r;
+    if (V == 4) { const uint32_t t = *(const uint32_t*)p; r.v[0] = (float)(t & 255u); r.v[1 % V] = (float)((t >> 8) & 255u); r.v[2 % V] = (float)((t >> 16) & 255u); r.v[3 % V] = (float)(t >> 24); }
+    else r.v[0] = (float)*p;
+    return r;
+}
+
 // x_t = z0 * t0, then the churn of inner iteration 0.
+template <int V>
 __global__ __launch_bounds__(256) void k_step_init(StepCommon c, float t0, float churn0, float c_in0) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < c.n_cells; e += (int64_t)gridDim.x * blockDim.x) {
-        const Cell k = cell_of(c, e);
-        float z0, zc;
-        if (c.noise) {
-            z0 = draw(c, k, 0);
-            zc = draw(c, k, 3);                      // iteration 0: draws 1 n_curr, 2 n_prev, 3 churn, 4 n
-        } else {
-            float a, b;
-            philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), DP_PHILOX_INIT_BLOCK, z0, a, zc, b);
+    const int64_t nv = c.n_cells / V;
+    for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < nv; ev += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = ev * V;
+        Cell k = cell_of(c, e);
+        VecF<V> xh, uu;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float z0, zc;
+            if (c.noise) {
+                z0 = draw(c, k, 0);
+                zc = draw(c, k, 3);                      // iteration 0: draws 1 n_curr, 2 n_prev, 3 churn, 4 n
+            } else {
+                float a, b;
+                philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), DP_PHILOX_INIT_BLOCK, z0, a, zc, b);
+            }
+            const float x_t = z0 * t0;
+            xh.v[v] = x_t + churn0 * zc;
+            uu.v[v] = c_in0 * xh.v[v];
+            ++k.col;
         }
-        const float x_t = z0 * t0;
-        const float xh = x_t + churn0 * zc;
-        c.x_hat[e] = xh;
-        store_u(c, k.m, k.col, c_in0 * xh);
+        stf<V>(c.x_hat + e, xh);
+        store_u<V>(c, k.m, k.col - V, uu);
     }
 }
 
+// Per-cell arithmetic after the first evaluation of an inner iteration at a Heun level (model.py:164,
+// diffusion_utils.py:100-101): shared by k_step_mid and by the GEMM epilogue that fuses it (dp_gemm_bf16_pp.h, EPI_MID).
+__device__ __forceinline__ void mid_step_cell(float xh, float Fx, float c_skip, float c_out, float t_hat, float h, float c_in_next,
+                                              float& d, float& u) {
+    const float den = c_skip * xh + c_out * Fx;
+    d = (xh - den) / t_hat;
+    const float xe = xh + h * d;
+    u = c_in_next * xe;
+}
+
 // After the first evaluation of an inner iteration at a Heun level.
+template <int V>
 __global__ __launch_bounds__(256) void k_step_mid(StepCommon c, float c_skip, float c_out, float t_hat, float h, float c_in_next) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < c.n_cells; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nv = c.n_cells / V;
+    for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < nv; ev += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = ev * V;
         const int64_t m = e / c.D;
         const int col = (int)(e - m * c.D);
-        const float xh = c.x_hat[e];
-        const float Fx = c.F[m * c.ldF + col];
-        const float den = c_skip * xh + c_out * Fx;
-        const float d = (xh - den) / t_hat;
-        const float xe = xh + h * d;
-        c.d_cur[e] = d;
-        store_u(c, m, col, c_in_next * xe);
+        const VecF<V> xh = ldf<V>(c.x_hat + e), Fx = ldf<V>(c.F + m * c.ldF + col);
+        VecF<V> dd, uu;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            mid_step_cell(xh.v[v], Fx.v[v], c_skip, c_out, t_hat, h, c_in_next, dd.v[v], uu.v[v]);
+        }
+        stf<V>(c.d_cur + e, dd);
+        store_u<V>(c, m, col, uu);
     }
 }
 
 // After the second evaluation: Heun, observed-value blend, re-noise, next churn.
 //   it = global inner-iteration index; renoise > 0 iff j < R-1; churn_next/c_in_next belong to iteration it+1.
+template <int V>
 __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_skip, float c_out, float t_next, float h,
                                                   float renoise, int add_renoise, float churn_next, float c_in_next) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < c.n_cells; e += (int64_t)gridDim.x * blockDim.x) {
-        const Cell k = cell_of(c, e);
-        float z_prev, z_re, z_churn;
-        if (c.noise) {
-            const int64_t base = 1 + 4 * (int64_t)it;
-            z_prev = draw(c, k, base + 1);
-            z_re = add_renoise ? draw(c, k, base + 3) : 0.f;
-            z_churn = draw(c, k, base + 4 + 2);      // churn draw of iteration it+1
-        } else {
-            float unused;
-            philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), (uint32_t)it, z_prev, z_re, z_churn, unused);
-        }
-        const float xh = c.x_hat[e];
-        const float d = c.d_cur[e];
-        const float xe = xh + h * d;
-        const float Fx = c.F[k.m * c.ldF + k.col];
-        const float den = c_skip * xe + c_out * Fx;
-        const float dp = (xe - den) / t_next;
-        const float xn = xh + h * (0.5f * d + 0.5f * dp);
+    const int64_t nv = c.n_cells / V;
+    for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < nv; ev += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = ev * V;
+        Cell k = cell_of(c, e);
         const int64_t oc = k.row * c.D + k.col;
-        const float mk = (float)c.mask[oc];
-        const float xk = c.x_obs[oc] + z_prev * t_next;
-        float x_t = xk * (1.0f - mk) + xn * mk;
-        if (add_renoise) x_t = x_t + z_re * renoise;
-        if (c.trace) c.trace[(int64_t)it * c.n_cells + e] = x_t;
-        const float xh2 = x_t + churn_next * z_churn;
-        c.x_hat[e] = xh2;
-        store_u(c, k.m, k.col, c_in_next * xh2);
+        const VecF<V> xhv = ldf<V>(c.x_hat + e), dv = ldf<V>(c.d_cur + e), Fv = ldf<V>(c.F + k.m * c.ldF + k.col);
+        const VecF<V> xov = ldf<V>(c.x_obs + oc), mkv = ldmask<V>(c.mask + oc);
+        VecF<V> xt, xh2, uu;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float z_prev, z_re, z_churn;
+            if (c.noise) {
+                const int64_t base = 1 + 4 * (int64_t)it;
+                z_prev = draw(c, k, base + 1);
+                z_re = add_renoise ? draw(c, k, base + 3) : 0.f;
+                z_churn = draw(c, k, base + 4 + 2);      // churn draw of iteration it+1
+            } else {
+                float unused;
+                philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), (uint32_t)it, z_prev, z_re, z_churn, unused);
+            }
+            const float xh = xhv.v[v], d = dv.v[v], mk = mkv.v[v];
+            const float xe = xh + h * d;
+            const float den = c_skip * xe + c_out * Fv.v[v];
+            const float dp = (xe - den) / t_next;
+            const float xn = xh + h * (0.5f * d + 0.5f * dp);
+            const float xk = xov.v[v] + z_prev * t_next;
+            float x_t = xk * (1.0f - mk) + xn * mk;
+            if (add_renoise) x_t = x_t + z_re * renoise;
+            xt.v[v] = x_t;
+            xh2.v[v] = x_t + churn_next * z_churn;
+            uu.v[v] = c_in_next * xh2.v[v];
+            ++k.col;
+        }
+        if (c.trace) stf<V>(c.trace + (int64_t)it * c.n_cells + e, xt);
+        stf<V>(c.x_hat + e, xh2);
+        store_u<V>(c, k.m, k.col - V, uu);
     }
 }
 
 // Last level (t_next = 0): Euler step = the denoised sample; blend; caller's blend; sum over this call's trials.
-// One thread per (row, col); trials are summed in order, so the result is deterministic.
+// One thread per V cells of (row, col); trials are summed in order, so the result is deterministic.
+template <int V>
 __global__ __launch_bounds__(256) void k_step_final(StepCommon c, int it, float c_skip, float c_out, float t_hat, float h,
                                                     float* __restrict__ out, int accumulate) {
     const int64_t per_trial = c.n_rows * c.D;
-    for (int64_t oc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; oc < per_trial; oc += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t ov = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ov < per_trial / V; ov += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t oc = ov * V;
         const int64_t row = oc / c.D;
         const int col = (int)(oc - row * c.D);
-        const float mk = (float)c.mask[oc];
-        const float xo = c.x_obs[oc];
-        float sum = accumulate ? out[oc] : 0.f;
+        const VecF<V> mkv = ldmask<V>(c.mask + oc), xov = ldf<V>(c.x_obs + oc);
+        VecF<V> sum;
+        if (accumulate) sum = ldf<V>(out + oc);
+        else for (int v = 0; v < V; ++v) sum.v[v] = 0.f;
         for (int tl = 0; tl < c.num_trials; ++tl) {
             const int64_t e = (int64_t)tl * per_trial + oc;
             const int64_t m = (int64_t)tl * c.n_rows + row;
-            const float xh = c.x_hat[e];
-            const float Fx = c.F[m * c.ldF + col];
-            const float den = c_skip * xh + c_out * Fx;
-            const float d = (xh - den) / t_hat;
-            const float xe = xh + h * d;
-            // x_known = x + randn * 0 = x (:60-62); blend (:65)
-            const float x_t = xo * (1.0f - mk) + xe * mk;
-            if (c.trace) c.trace[(int64_t)it * c.n_cells + e] = x_t;
-            sum = sum + (x_t * mk + xo * (1.0f - mk));       // main.py:183
+            const VecF<V> xhv = ldf<V>(c.x_hat + e), Fv = ldf<V>(c.F + m * c.ldF + col);
+            VecF<V> xt;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float xh = xhv.v[v], mk = mkv.v[v], xo = xov.v[v];
+                const float den = c_skip * xh + c_out * Fv.v[v];
+                const float d = (xh - den) / t_hat;
+                const float xe = xh + h * d;
+                // x_known = x + randn * 0 = x (:60-62); blend (:65)
+                const float x_t = xo * (1.0f - mk) + xe * mk;
+                xt.v[v] = x_t;
+                sum.v[v] = sum.v[v] + (x_t * mk + xo * (1.0f - mk));       // main.py:183
+            }
+            if (c.trace) stf<V>(c.trace + (int64_t)it * c.n_cells + e, xt);
         }
-        out[oc] = sum;
+        stf<V>(out + oc, sum);
     }
 }
 

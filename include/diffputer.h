@@ -157,6 +157,9 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
  *   "fold_proj"     1 (default) = in DP_DTYPE_BF16 plans proj and mlp.0 run as ONE Linear, (W0 Wp) u + (W0 (proj.bias + emb) + b0): no
  *                   activation separates them (model.py:126-128), so this is the same function with one rounding
  *                   of h0 fewer; 0 = two GEMMs as in the reference's module list.  Read at every evaluation.
+ *   "fuse_mid"      1 (default) = for bf16 plans with d_in = 256 the arithmetic after a Heun iteration's first evaluation
+ *                   (diffusion_utils.py:100-101) runs in the epilogue of the mlp.6 GEMM instead of a kernel of its own;
+ *                   bit-identical results.
  */
 int dp_tune(const char* key, int value);
 

@@ -301,6 +301,28 @@ def test_sharding_and_batching_invariance():
         p.close()
 
 
+def test_fused_mid_step_bit_identical():
+    """d_in = 256: the mid step inside the mlp.6 GEMM epilogue (dp_tune fuse_mid=1) vs the stand-alone k_step_mid."""
+    from diffputer_amd import _lib
+    d, hid, S, R, n, T = 256, 256, 4, 3, 301, 2                      # 602 chains -> 768 GEMM rows: padding rows are skipped
+    sd = synth.make_weights(d, hid, 91, 1.5)
+    X, mask = synth.make_table(n, d, seed=92)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    lib = _lib.load()
+    outs = []
+    try:
+        for fuse in (1, 0):
+            _lib.check(lib.dp_tune(b"fuse_mid", fuse), "dp_tune")
+            p = _plan(sd, S, R, "bf16")
+            out, tr = p.impute_sum(x_obs, mask, T, seed=17, trace=True)
+            outs.append((out.clone(), tr.clone()))
+            p.close()
+    finally:
+        _lib.check(lib.dp_tune(b"fuse_mid", 1), "dp_tune")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool(torch.isfinite(outs[0][0]).all())
+
+
 def test_column_major_table_and_out_validation():
     """A pandas-derived (column-major) table must give the result of its row-major copy; a strided `out` is refused."""
     from diffputer_amd import estep
