@@ -27,18 +27,41 @@ def shard_bounds(n_rows: int, world_size: int, rank: int):
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
+ROUND_CHAINS = 8192   # chains one round of the persistent GEMM covers at N = 2048: 256 CUs x 256-row tiles / 8 column tiles
+
+
+def _call_cost(chains: int) -> int:
+    """Relative cost of a dp_impute call: whole GEMM rounds, plus a fixed per-call part (launch-bound tail of every kernel)."""
+    return -(-chains // ROUND_CHAINS) * ROUND_CHAINS + 1024
+
+
 def plan_calls(n_rows: int, num_trials: int, max_chains: int):
-    """Split rows x trials into dp_impute calls of at most `max_chains` chains.
-    Yields (r0, r1, t0, t1).  Small tables batch several trials per call; large ones chunk rows."""
-    if n_rows >= max_chains:
-        for r0 in range(0, n_rows, max_chains):
-            for t in range(num_trials):
-                yield r0, min(n_rows, r0 + max_chains), t, t + 1
-    else:
-        per = max(1, max_chains // n_rows)
-        per = -(-num_trials // -(-num_trials // per))                      # same number of calls, equal sizes
-        for t0 in range(0, num_trials, per):
-            yield 0, n_rows, t0, min(num_trials, t0 + per)
+    """Split rows x trials into rectangular dp_impute calls (r0, r1, t0, t1) of at most `max_chains` chains each.
+
+    Chains are independent, so any partition gives the same numbers; what differs is how well each call fills the
+    GPU: the GEMMs walk 256-row tiles in rounds of one tile per CU, so 32 770 chains cost five rounds where 32 768 cost
+    four.  Among the splits into k equal row chunks x equal trial batches this picks the cheapest by `_call_cost`."""
+    best = None
+    for k in range(1, 65):
+        rows = -(-n_rows // k)
+        if rows > max_chains:
+            continue
+        per_max = max(1, min(num_trials, max_chains // rows))
+        for per in {per_max, -(-num_trials // -(-num_trials // per_max))}:   # fullest batches / equal batches
+            calls = []
+            for r0 in range(0, n_rows, rows):
+                r1 = min(n_rows, r0 + rows)
+                for t0 in range(0, num_trials, per):
+                    calls.append((r0, r1, t0, min(num_trials, t0 + per)))
+            cost = sum(_call_cost((c[1] - c[0]) * (c[3] - c[2])) for c in calls)
+            if best is None or cost < best[0]:
+                best = (cost, calls)
+        if rows * num_trials <= ROUND_CHAINS:
+            break
+    if best is None:                                              # more rows than chains per call even at k = 64
+        calls = [(r0, min(n_rows, r0 + max_chains), t, t + 1) for r0 in range(0, n_rows, max_chains) for t in range(num_trials)]
+        return iter(calls)
+    return iter(best[1])
 
 
 def impute_trials(plan: SamplerPlan, X, mask, num_trials: int, *, seed: int = 0, row_offset: int = 0,
