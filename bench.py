@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--trials", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--max-chains", type=int, default=1 << 16)
-    ap.add_argument("--cpu-rows", type=int, default=192, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=512, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
     a = ap.parse_args()
