@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdiffputer_hip.so")
 DP_DTYPE_F32 = 0
 DP_DTYPE_BF16 = 1
 DP_ACCUMULATE = 1
+DP_NO_FINAL_LEVEL = 2
 
 # every symbol include/diffputer.h declares: (restype, argtypes)
 _vp, _i, _i64, _u64, _u32, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_float, C.c_size_t

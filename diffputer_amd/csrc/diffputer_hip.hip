@@ -431,14 +431,15 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
         return fail(DP_EWORKSPACE, "workspace of %zu bytes is too small for %lld chains (need %zu)", workspace_bytes, (long long)M, w.bytes);
     hipStream_t st = (hipStream_t)stream;
     const int S = p->S, R = p->R, D = p->d_in;
-    const int n_iter = R * (S - 1) + 1;
+    const bool no_final = (flags & DP_NO_FINAL_LEVEL) != 0;
+    const int n_iter = R * (S - 1) + (no_final ? 0 : 1);
 
     StepCommon c;
     c.x_hat = w.x_hat; c.d_cur = w.d_cur; c.F = w.F; c.u = w.u;
     c.x_obs = x_obs; c.mask = mask; c.noise = noise; c.trace = trace;
     c.n_cells = M * D; c.n_rows = n_rows;
     c.draw_stride = n_rows * D;
-    c.trial_stride = (int64_t)(1 + 4 * (int64_t)R * (S - 1) + 3) * c.draw_stride;
+    c.trial_stride = (int64_t)(1 + 4 * (int64_t)R * (S - 1) + (no_final ? 0 : 3)) * c.draw_stride;
     c.seed = seed; c.row_offset = row_offset;
     c.D = D; c.ldF = p->N5; c.ldu = p->K1; c.u_bf16 = p->dtype == DP_DTYPE_BF16;
     c.trial_offset = trial_offset; c.num_trials = num_trials;
@@ -478,8 +479,11 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
             if ((rc = eval_F(p, w, 2 * i + 1, st, ev))) return rc;
             const int add_re = j < R - 1;
             const int i_next = std::min((it + 1) / R, S - 1);
+            const bool last = no_final && it == n_iter - 1;       // then d_cur, read by this launch cell by cell, receives x_t
             DP_STEP(k_step_end, g, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re, p->churn[i_next],
-                    p->lv[2 * i_next].c.c_in);
+                    p->lv[2 * i_next].c.c_in, last ? w.d_cur : (float*)nullptr);
+            if (last)
+                DP_STEP(k_blend_sum, grid_for(n_rows * D / (vec ? 4 : 1)), c, (const float*)w.d_cur, out, (flags & DP_ACCUMULATE) ? 1 : 0);
             if (ev) DP_HIP(hipEventRecord(ev[6], st));
         } else {
             DP_STEP(k_step_final, grid_for(n_rows * D / (vec ? 4 : 1)), c, it, l0.c.c_skip, l0.c.c_out, p->th[i], h, out,

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_step_mid(StepCommon c, float c_skip, fl
 //   it = global inner-iteration index; renoise > 0 iff j < R-1; churn_next/c_in_next belong to iteration it+1.
 template <int V>
 __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_skip, float c_out, float t_next, float h,
-                                                  float renoise, int add_renoise, float churn_next, float c_in_next) {
+                                                  float renoise, int add_renoise, float churn_next, float c_in_next,
+                                                  float* __restrict__ xt_out) {
     const int64_t nv = c.n_cells / V;
     for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < nv; ev += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = ev * V;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_
             ++k.col;
         }
         if (c.trace) stf<V>(c.trace + (int64_t)it * c.n_cells + e, xt);
+        if (xt_out) stf<V>(xt_out + e, xt);                       // DP_NO_FINAL_LEVEL: x_t itself is the result
         stf<V>(c.x_hat + e, xh2);
         store_u<V>(c, k.m, k.col - V, uu);
     }
@@ -223,6 +225,25 @@ __global__ __launch_bounds__(256) void k_step_final(StepCommon c, int it, float 
                 sum.v[v] = sum.v[v] + (x_t * mk + xo * (1.0f - mk));       // main.py:183
             }
             if (c.trace) stf<V>(c.trace + (int64_t)it * c.n_cells + e, xt);
+        }
+        stf<V>(out + oc, sum);
+    }
+}
+
+// DP_NO_FINAL_LEVEL: the caller's blend and trial sum over x_t [M, D] (main.py:182-188), trials in order.
+template <int V>
+__global__ __launch_bounds__(256) void k_blend_sum(StepCommon c, const float* __restrict__ xt, float* __restrict__ out, int accumulate) {
+    const int64_t per_trial = c.n_rows * c.D;
+    for (int64_t ov = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ov < per_trial / V; ov += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t oc = ov * V;
+        const VecF<V> mkv = ldmask<V>(c.mask + oc), xov = ldf<V>(c.x_obs + oc);
+        VecF<V> sum;
+        if (accumulate) sum = ldf<V>(out + oc);
+        else for (int v = 0; v < V; ++v) sum.v[v] = 0.f;
+        for (int tl = 0; tl < c.num_trials; ++tl) {
+            const VecF<V> x = ldf<V>(xt + (int64_t)tl * per_trial + oc);
+#pragma unroll
+            for (int v = 0; v < V; ++v) sum.v[v] = sum.v[v] + (x.v[v] * mkv.v[v] + xov.v[v] * (1.0f - mkv.v[v]));
         }
         stf<V>(out + oc, sum);
     }

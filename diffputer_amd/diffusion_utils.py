@@ -92,13 +92,23 @@ def sample_step(net, num_steps, i, t_cur, t_next, x_next, *, eps=None, seed=None
     return plan.sample_step(int(i), float(t_cur), float(t_next), x_next, eps, seed=seed)
 
 
-def sample(net, num_samples, dim, num_steps=50, device="cuda:0", *, seed=None, dtype=None):
+def sample(net, num_samples, dim, num_steps=50, device="cuda:0", *, seed=None, dtype=None, noise=None):
     """Unconditional EDM sampler (diffusion_utils.py:70-88; not called by main.py): the same kernels
-    with every cell missing and no resampling."""
+    with every cell missing and no resampling.
+    noise: optional [1 + num_steps, N, D] replay of the reference's draws (latents, then one churn draw per level)."""
     plan = plan_for(net, num_steps, device, dtype, n_resample=1)
     if seed is None:
         seed = next(_seed_counter)
     x = torch.zeros((num_samples, dim), dtype=torch.float32, device=device)
     m = torch.ones((num_samples, dim), dtype=torch.uint8, device=device)
-    out, _ = plan.impute_sum(x, m, 1, seed=seed)
+    nz = None
+    if noise is not None:
+        # impute_mask's draw order with R = 1: draw 0, then per level (n_curr, n_prev, churn, n); only churn is live here
+        src = torch.as_tensor(noise).to(device, torch.float32)
+        from .sampler import n_draws
+        nz = torch.zeros((n_draws(num_steps, 1), num_samples, dim), dtype=torch.float32, device=device)
+        nz[0] = src[0]
+        for i in range(num_steps):
+            nz[1 + 4 * i + 2] = src[1 + i]
+    out, _ = plan.impute_sum(x, m, 1, seed=seed, noise=nz)
     return out

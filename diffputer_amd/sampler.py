@@ -31,12 +31,12 @@ def _state_dict_of(net_or_sd) -> dict:
     return out
 
 
-def n_draws(num_steps: int, n_resample: int) -> int:
-    return 1 + 4 * n_resample * (num_steps - 1) + 3
+def n_draws(num_steps: int, n_resample: int, final_level: bool = True) -> int:
+    return 1 + 4 * n_resample * (num_steps - 1) + (3 if final_level else 0)
 
 
-def n_iter(num_steps: int, n_resample: int) -> int:
-    return n_resample * (num_steps - 1) + 1
+def n_iter(num_steps: int, n_resample: int, final_level: bool = True) -> int:
+    return n_resample * (num_steps - 1) + (1 if final_level else 0)
 
 
 class SamplerPlan:
@@ -142,9 +142,9 @@ class SamplerPlan:
         return x, m
 
     def impute_sum(self, x_obs, mask, num_trials: int = 1, *, seed: int = 0, row_offset: int = 0, trial_offset: int = 0,
-                   noise=None, trace: bool = False, out=None, accumulate: bool = False):
+                   noise=None, trace: bool = False, out=None, accumulate: bool = False, final_level: bool = True):
         """One `dp_impute` call: all `num_trials` trials of all rows as one batch of chains.
-        Returns (sum over trials [n, D], trace or None)."""
+        Returns (sum over trials [n, D], trace or None).  final_level=False: DP_NO_FINAL_LEVEL (the MissDiff variant)."""
         x, m = self._prep(x_obs, mask)
         n = x.shape[0]
         if n == 0:
@@ -158,20 +158,21 @@ class SamplerPlan:
         nz = None
         if noise is not None:
             nz = torch.as_tensor(noise).to(self.device, torch.float32).contiguous()
-            want = (num_trials, n_draws(self.num_steps, self.n_resample), n, self.d_in)
+            want = (num_trials, n_draws(self.num_steps, self.n_resample, final_level), n, self.d_in)
             if nz.ndim == 3:
                 nz = nz.unsqueeze(0)
             if tuple(nz.shape) != want:
                 raise ValueError(f"noise has shape {tuple(nz.shape)}, expected {want}")
         tr = None
         if trace:
-            tr = torch.empty((n_iter(self.num_steps, self.n_resample), num_trials, n, self.d_in), dtype=torch.float32,
+            tr = torch.empty((n_iter(self.num_steps, self.n_resample, final_level), num_trials, n, self.d_in), dtype=torch.float32,
                              device=self.device)
         ws = self._workspace(n * num_trials)
         with torch.cuda.device(self.device):
             rc = self.lib.dp_impute(self._h, x.data_ptr(), m.data_ptr(), out.data_ptr(), n, int(num_trials), int(seed),
                                     int(row_offset), int(trial_offset), nz.data_ptr() if nz is not None else None,
-                                    tr.data_ptr() if tr is not None else None, _lib.DP_ACCUMULATE if accumulate else 0,
+                                    tr.data_ptr() if tr is not None else None,
+                                    (_lib.DP_ACCUMULATE if accumulate else 0) | (0 if final_level else _lib.DP_NO_FINAL_LEVEL),
                                     ws.data_ptr(), ws.numel(), self._stream())
         _lib.check(rc, "dp_impute")
         return out, tr

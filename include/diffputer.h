@@ -38,7 +38,10 @@ extern "C" {
 #define DP_DTYPE_BF16    1   /* GEMM operands bfloat16, fp32 accumulate, v_mfma_f32_16x16x32_bf16 */
 
 /* dp_impute flags */
-#define DP_ACCUMULATE    1   /* out += sum over this call's trials (default: out = sum) */
+#define DP_ACCUMULATE     1  /* out += sum over this call's trials (default: out = sum) */
+#define DP_NO_FINAL_LEVEL 2  /* stop after the last resampled level and return x_t at sigma_min: the impute_mask of
+                                baselines/Missdiff_SDE/diffusion_utils.py:24-60, whose last level has no else branch
+                                (create the plan with n_resample = 10 for that baseline) */
 
 typedef struct dp_plan dp_plan;
 
@@ -90,11 +93,12 @@ size_t dp_workspace_bytes(const dp_plan* plan, int64_t n_chains);
  *              counter-based Philox4x32-10 noise keyed by (seed; global row = row_offset + r, global trial =
  *              trial_offset + t, column, draw block): results do not depend on how rows/trials are sharded.
  *   noise      NULL, or [num_trials, n_draws, n_rows, d_in] float32: the reference's Gaussian draws in
- *              program order (n_draws = 1 + 4*R*(S-1) + 3; draw 0 = torch.randn :25, then per inner iteration
- *              n_curr :44 (unused), n_prev :45, churn eps :96, n :52).  Used instead of Philox: parity mode.
+ *              program order (n_draws = 1 + 4*R*(S-1) + 3, without the + 3 under DP_NO_FINAL_LEVEL; draw 0 =
+ *              torch.randn :25, then per inner iteration n_curr :44 (unused), n_prev :45, churn eps :96, n :52).
+ *              Used instead of Philox: parity mode.
  *   trace      NULL, or [n_iter, num_trials, n_rows, d_in] float32 receiving x_t after every inner iteration
- *              (n_iter = R*(S-1) + 1).
- *   flags      DP_ACCUMULATE or 0
+ *              (n_iter = R*(S-1) + 1; R*(S-1) under DP_NO_FINAL_LEVEL).
+ *   flags      DP_ACCUMULATE | DP_NO_FINAL_LEVEL or 0
  */
 int dp_impute(dp_plan* plan, const float* x_obs, const uint8_t* mask, float* out,
               int64_t n_rows, int num_trials, uint64_t seed, uint64_t row_offset, int trial_offset,

@@ -141,7 +141,7 @@ def sample_step(sd: dict, num_steps: int, i: int, t_cur, t_next, x_cur: np.ndarr
 
 
 def impute_mask(sd: dict, x: np.ndarray, mask: np.ndarray, noise, num_steps: int = 50,
-                n_resample: int = N_RESAMPLE, trace: list | None = None) -> np.ndarray:
+                n_resample: int = N_RESAMPLE, trace: list | None = None, final_level: bool = True) -> np.ndarray:
     """Masked reverse diffusion with RePaint resampling (diffusion_utils.py:23-68).
 
     x      [N, D] float32, observed values (anything at missing cells; the reference passes 0)
@@ -151,6 +151,9 @@ def impute_mask(sd: dict, x: np.ndarray, mask: np.ndarray, noise, num_steps: int
            churn eps (:96, inside sample_step), n (:52, drawn always, used iff j < R-1);
            the last level draws only the first three (:59-63).
     trace  if a list, x_t after every inner iteration is appended (float32 copies).
+    final_level  False = the MissDiff baseline's variant (baselines/Missdiff_SDE/diffusion_utils.py:24-60, which uses
+           n_resample = 10): its loop body is guarded by `if i < num_steps - 1` with no else branch, so the last level
+           does nothing, draws nothing, and x_t at sigma_min is returned.
     """
     x = np.asarray(x, dtype=F32)
     m = np.asarray(mask).astype(np.int32).astype(F32)       # :34, used arithmetically at :50
@@ -158,7 +161,7 @@ def impute_mask(sd: dict, x: np.ndarray, mask: np.ndarray, noise, num_steps: int
     k = 0
     x_t = (np.asarray(noise[k], dtype=F32) * t[0]).astype(F32)      # :25,:35
     k += 1
-    for i in range(num_steps):
+    for i in range(num_steps if final_level else num_steps - 1):
         t_cur, t_next = t[i], t[i + 1]
         reps = n_resample if i < num_steps - 1 else 1               # :41-43 / :58
         for j in range(reps):
@@ -179,6 +182,16 @@ def impute_mask(sd: dict, x: np.ndarray, mask: np.ndarray, noise, num_steps: int
             if trace is not None:
                 trace.append(x_t.copy())
     return x_t
+
+
+def sample(sd: dict, noise, num_steps: int = 50) -> np.ndarray:
+    """Unconditional EDM sampler (diffusion_utils.py:70-88; not called by main.py).
+    noise[0] = the latents draw (:71), noise[1 + i] = the churn draw of level i."""
+    t = sigma_schedule(num_steps)
+    x_next = (np.asarray(noise[0], dtype=F32) * t[0]).astype(F32)          # :82
+    for i in range(num_steps):
+        x_next = sample_step(sd, num_steps, i, t[i], t[i + 1], x_next, np.asarray(noise[1 + i], dtype=F32))   # :86
+    return x_next
 
 
 def e_step(sd: dict, X: np.ndarray, mask: np.ndarray, noise_per_trial, num_trials: int,

@@ -323,6 +323,39 @@ def test_fused_mid_step_bit_identical():
     assert bool(torch.isfinite(outs[0][0]).all())
 
 
+def _torch_net(g):
+    from diffputer_amd.model import MLPDiffusion, Model
+    model = Model(denoise_fn=MLPDiffusion(int(g["d_in"]), int(g["hid"])), hid_dim=int(g["d_in"])).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(g).items()})
+    return model.denoise_fn_D
+
+
+def test_unconditional_sample_golden():
+    """`sample` (diffusion_utils.py:70-88) with the reference's draws replayed."""
+    from diffputer_amd import diffusion_utils as du
+    g = load_golden("sample_D9_H64_S10")
+    out = du.sample(_torch_net(g), int(g["n"]), int(g["d_in"]), int(g["S"]), DEV, noise=g["noise"], dtype="f32")
+    rel_check(out.cpu().numpy(), g["out"], floor=1e-3, what="sample")
+    a = du.sample(_torch_net(g), 64, int(g["d_in"]), int(g["S"]), DEV, seed=1)
+    assert a.shape == (64, 9) and bool(torch.isfinite(a).all())
+
+
+def test_missdiff_variant_golden():
+    """the MissDiff baseline's impute_mask (N = 10, no final level) with its draws replayed."""
+    from diffputer_amd import missdiff
+    g = load_golden("missdiff_D9_H64_S10")
+    net = _torch_net(g)
+    x = torch.from_numpy(g["x_obs"]).to(DEV)
+    m = torch.from_numpy(g["mask"])
+    out = missdiff.impute_mask(net, x, m, int(g["n"]), int(g["d_in"]), int(g["S"]), DEV, noise=g["noise"], dtype="f32").cpu().numpy()
+    mk = g["mask"]
+    rel_check(out[mk], g["out"][mk], floor=1e-3, what="missdiff, missing cells")
+    assert np.array_equal(out[~mk], g["x_obs"][~mk])              # blended like main.py:182-183; the reference returns x + 0.002 n there
+    assert float(np.abs(g["out"][~mk] - g["x_obs"][~mk]).max()) < 0.02
+    b = missdiff.impute_mask(net, x, m, int(g["n"]), int(g["d_in"]), int(g["S"]), DEV, noise=g["noise"], dtype="bf16").cpu().numpy()
+    assert float(np.abs(b[mk] - g["out"][mk]).max()) <= 1e-1 * max(1.0, float(np.abs(g["out"]).max()))
+
+
 def test_column_major_table_and_out_validation():
     """A pandas-derived (column-major) table must give the result of its row-major copy; a strided `out` is refused."""
     from diffputer_amd import estep

@@ -140,3 +140,13 @@ def test_trained_checkpoint_replay():
     close(out, g["replay_out"], atol=2e-5, rtol=1e-4)
     mae, rmse = mae_rmse(out * 2, X * 2, m)
     assert abs(mae - g["replay_mae_rmse"][0]) < 1e-5 and abs(rmse - g["replay_mae_rmse"][1]) < 1e-5
+
+
+def test_variants_sample_and_missdiff():
+    """`sample` and the MissDiff baseline's impute_mask (N = 10, no final level), both run from the reference."""
+    g = load_golden("sample_D9_H64_S10")
+    sd = synth.make_weights(int(g["d_in"]), int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+    close(orc.sample(sd, g["noise"], int(g["S"])), g["out"], atol=1e-5, rtol=1e-4)
+    g = load_golden("missdiff_D9_H64_S10")
+    out = orc.impute_mask(sd, g["x_obs"], g["mask"], g["noise"], int(g["S"]), int(g["R"]), final_level=False)
+    close(out, g["out"], atol=1e-5, rtol=1e-4)

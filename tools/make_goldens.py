@@ -244,7 +244,38 @@ def gold_estep():
          nseeds=np.asarray([610, 611, 612]), X=X, mask=mask, mean=mean.numpy())
 
 
-ALL = {"schedule": gold_schedule, "embedding": gold_embedding, "denoiser": gold_denoiser,
+def gold_variants():
+    """the unconditional sampler `sample` (diffusion_utils.py:70-88) and the MissDiff baseline's
+    impute_mask (baselines/Missdiff_SDE/diffusion_utils.py:24-60: N = 10 and no final level)."""
+    import importlib.util
+    d_in, hid, S, n = 9, 64, 10, 8
+    net, _ = ref_net(d_in, hid, 700, 2.0)
+    stream = synth.reference_noise(701, 1 + S, (n, d_in))
+    with NoiseReplay(stream) as nr:
+        out = ref_du.sample(net, n, d_in, S, "cpu")
+        assert nr.k == 1 + S
+    save("sample_D9_H64_S10", wseed=700, gain=2.0, d_in=d_in, hid=hid, S=S, n=n, noise=stream, out=out.numpy())
+
+    spec = importlib.util.spec_from_file_location("missdiff_du", os.path.join(REF, "baselines", "Missdiff_SDE", "diffusion_utils.py"))
+    md = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(md)
+    R = 10
+    X, mask = synth.make_table(n, d_in, seed=712)
+    x_obs = (X * (1.0 - mask.astype(np.float32))).astype(np.float32)
+    stream = synth.reference_noise(711, 1 + 4 * R * (S - 1), (n, d_in))
+    saved = md.randn_like
+    with NoiseReplay(stream) as nr:
+        md.randn_like = torch.randn_like                      # the module-level alias (:13) must see the patched function
+        try:
+            out = md.impute_mask(net, torch.from_numpy(x_obs), torch.from_numpy(mask), n, d_in, S, "cpu")
+        finally:
+            md.randn_like = saved
+        assert nr.k == stream.shape[0], (nr.k, stream.shape)
+    save("missdiff_D9_H64_S10", wseed=700, gain=2.0, d_in=d_in, hid=hid, S=S, R=R, n=n, noise=stream, X=X, mask=mask,
+         x_obs=x_obs, out=out.numpy())
+
+
+ALL = {"variants": gold_variants, "schedule": gold_schedule, "embedding": gold_embedding, "denoiser": gold_denoiser,
        "sample_step": gold_sample_step, "impute": gold_impute, "estep": gold_estep}
 
 if __name__ == "__main__":
