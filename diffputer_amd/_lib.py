@@ -36,6 +36,8 @@ SIGNATURES = {
     "dp_plan_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "dp_tune": (_i, [C.c_char_p, _i]),
     "dp_linear": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "dp_masked_mean_std": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dp_masked_errors": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "dp_noise_field": (_i, [_vp, _i64, _i, _u64, _u64, _i, _u32, _i, _vp]),
 }
 

@@ -11,6 +11,7 @@
 #include "dp_gemm_bf16_pp.h"
 #include "dp_gemm_f32.h"
 #include "dp_philox.h"
+#include "dp_prep.h"
 #include "dp_step.h"
 #include "dp_util.h"
 
@@ -658,6 +659,38 @@ int dp_tune(const char* key, int value) {
         return DP_OK;
     }
     return fail(DP_EINVAL, "unknown tuning key '%s'", key);
+}
+
+int dp_masked_mean_std(const float* X, const uint8_t* mask, int64_t n_rows, int d, float* mean, float* std_out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (!X || !mask || !mean || !std_out || !workspace) return fail(DP_EINVAL, "NULL argument");
+    if (n_rows <= 0 || d < 1 || d > 4096) return fail(DP_EINVAL, "need n_rows > 0 and 1 <= d <= 4096");
+    if (workspace_bytes < (size_t)2 * d * sizeof(double) || ((uintptr_t)workspace & 7)) return fail(DP_EWORKSPACE, "workspace: need %zu bytes, 8-byte aligned", (size_t)2 * d * sizeof(double));
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = (double*)workspace;
+    double* cnt = acc + d;
+    DP_HIP(hipMemsetAsync(workspace, 0, (size_t)2 * d * sizeof(double), st));
+    const int rows_per_block = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div<int64_t>(n_rows, 2048), 1 << 20));
+    const int blocks = (int)ceil_div<int64_t>(n_rows, rows_per_block);
+    const size_t lds = (size_t)2 * d * sizeof(double);
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_col_stats, dim3(blocks), dim3(256), lds, st, X, mask, n_rows, d, pass, (const float*)mean, acc, cnt, rows_per_block);
+        DP_LAUNCH_CHECK("k_col_stats");
+        hipLaunchKernelGGL(k_col_finish, dim3(ceil_div(d, 256)), dim3(256), 0, st, d, pass, acc, (const double*)cnt, pass == 0 ? mean : std_out);
+        DP_LAUNCH_CHECK("k_col_finish");
+    }
+    return DP_OK;
+}
+
+int dp_masked_errors(const float* pred, const float* truth, const uint8_t* mask, int64_t n_rows, int d, int ld_mask, int num_num,
+                     double* sums, void* stream) {
+    if (!pred || !truth || !mask || !sums) return fail(DP_EINVAL, "NULL argument");
+    if (n_rows <= 0 || d < 1 || num_num < 1 || num_num > d || ld_mask < num_num) return fail(DP_EINVAL, "need n_rows > 0, 1 <= num_num <= d, ld_mask >= num_num");
+    hipStream_t st = (hipStream_t)stream;
+    DP_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), st));
+    hipLaunchKernelGGL(k_masked_errors, dim3(grid_for(n_rows * d)), dim3(256), 0, st, pred, truth, mask, n_rows * d, d, ld_mask, num_num, sums);
+    DP_LAUNCH_CHECK("k_masked_errors");
+    return DP_OK;
 }
 
 int dp_noise_field(float* out, int64_t n_rows, int d_in, uint64_t seed, uint64_t row_offset, int trial, uint32_t block, int comp,

@@ -24,3 +24,14 @@ def mae_rmse(pred, true, mask, num_num: int | None = None, drop_rows=None):
     if div.size == 0:
         raise ValueError("no masked numeric cell to score")
     return float(np.abs(div).mean()), float(np.sqrt((div ** 2).mean()))
+
+
+def mean_std(data, mask):
+    """Per-column mean / std over the OBSERVED cells (mask False), float32 like the reference (dataset.py:161-169)."""
+    obs = (~np.asarray(mask).astype(bool)).astype(np.float32)
+    data = np.asarray(data, dtype=np.float32)
+    cnt = obs.sum(0)
+    cnt[cnt == 0] = 1
+    mean = (data * obs).sum(0) / cnt
+    var = ((data - mean) ** 2 * obs).sum(0) / cnt
+    return mean, np.sqrt(var)

@@ -168,6 +168,24 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
 int dp_tune(const char* key, int value);
 
 /*
+ * Masked column statistics on the device.  Replaces: mean_std(data, mask) (dataset.py:161-169) as main.py:55 calls it:
+ * per column, mean and (population) std over the OBSERVED cells (mask == 0); a column with no observed cell gets
+ * count 1 like the reference (:164).  X [n_rows, d] float32 row-major, mask [n_rows, d] uint8, mean/std_out [d] float32
+ * device pointers; workspace >= 2*d*8 bytes of device memory.  Asynchronous on `stream`.
+ */
+int dp_masked_mean_std(const float* X, const uint8_t* mask, int64_t n_rows, int d, float* mean, float* std_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Scoring sums on the device.  Replaces: the arithmetic of get_eval (dataset.py:199-201): over the MISSING cells
+ * (mask == 1) of the first num_num (numeric) columns, sums[0] = sum |pred - truth|, sums[1] = sum (pred - truth)^2,
+ * sums[2] = count, float64 on the device; MAE = sums[0]/sums[2], RMSE = sqrt(sums[1]/sums[2]).
+ * pred, truth [n_rows, d]; mask [n_rows, ld_mask] (the ORIGINAL-column mask of dataset.py:183 may be wider than d).
+ */
+int dp_masked_errors(const float* pred, const float* truth, const uint8_t* mask, int64_t n_rows, int d, int ld_mask,
+                     int num_num, double* sums, void* stream);
+
+/*
  * Fill out[n_rows, d_in] with the Philox Gaussian field of draw block `block`, component `comp` (0..3), for
  * global rows row_offset.. and global trial `trial` (the noise dp_impute uses when noise == NULL).
  * No counterpart in the reference (it uses torch's global RNG, unseeded).

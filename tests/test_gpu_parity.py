@@ -356,6 +356,34 @@ def test_missdiff_variant_golden():
     assert float(np.abs(b[mk] - g["out"][mk]).max()) <= 1e-1 * max(1.0, float(np.abs(g["out"]).max()))
 
 
+def test_device_prep_and_scoring_golden():
+    """masked mean/std and MAE/RMSE reductions on the device against the reference's numbers."""
+    from diffputer_amd import prep
+    g = load_golden("prep_california")
+    X = torch.from_numpy(g["X"]).to(DEV)
+    m = torch.from_numpy(g["mask"]).to(DEV)
+    mean, std = prep.masked_mean_std(X, m)
+    assert np.allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=0), np.abs(mean.cpu().numpy() / g["mean"] - 1).max()
+    assert np.allclose(std.cpu().numpy(), g["std"], rtol=1e-5, atol=0), np.abs(std.cpu().numpy() / g["std"] - 1).max()
+    Xn = prep.normalize(X, mean, std)
+    # longitude is ~-119.6 with std 2.0: one float32 ulp of the mean (the reference sums in float32) is 4e-6 of a std
+    assert np.allclose(Xn.cpu().numpy(), g["Xn"], rtol=1e-4, atol=5e-5)
+    mae, rmse = prep.masked_errors(torch.from_numpy(g["pred"]).to(DEV), torch.from_numpy(g["Xn"]).to(DEV) * 2,
+                                   torch.from_numpy(g["ori_mask"]).to(DEV), num_num=X.shape[1])      # mask one column wider
+    assert abs(mae - float(g["mae"])) < 1e-6 and abs(rmse - float(g["rmse"])) < 1e-6
+    # a column with no observed cell: count 1 like the reference (dataset.py:164) -> mean 0, std 0
+    m2 = m.clone(); m2[:, 3] = True
+    mean2, std2 = prep.masked_mean_std(X, m2)
+    assert float(mean2[3]) == 0.0 and float(std2[3]) == 0.0 and torch.equal(mean2[:3], mean[:3])
+    # wide table, ragged size
+    Xw = torch.randn(3001, 257, device=DEV); mw = torch.rand(3001, 257, device=DEV) < 0.3
+    mw_f = (~mw).float()
+    mean_w, std_w = prep.masked_mean_std(Xw, mw)
+    ref_mean = (Xw * mw_f).sum(0) / mw_f.sum(0)
+    ref_std = (((Xw - ref_mean) ** 2 * mw_f).sum(0) / mw_f.sum(0)).sqrt()
+    assert torch.allclose(mean_w, ref_mean, rtol=1e-4, atol=1e-6) and torch.allclose(std_w, ref_std, rtol=1e-4, atol=1e-6)
+
+
 def test_column_major_table_and_out_validation():
     """A pandas-derived (column-major) table must give the result of its row-major copy; a strided `out` is refused."""
     from diffputer_amd import estep

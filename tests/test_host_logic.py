@@ -141,3 +141,15 @@ def test_gather_rows_world_size_2_gloo(n):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_prep_helpers_match_reference():
+    """evalmetrics.mean_std / mae_rmse against the reference's mean_std (dataset.py:161-169) and get_eval (:171-206)
+    run on 2 048 california rows (tools/make_prep_golden.py)."""
+    from conftest import load_golden
+    from diffputer_amd.evalmetrics import mae_rmse, mean_std
+    g = load_golden("prep_california")
+    mean, std = mean_std(g["X"], g["mask"])
+    assert np.allclose(mean, g["mean"], rtol=1e-6, atol=0) and np.allclose(std, g["std"], rtol=1e-6, atol=0)
+    mae, rmse = mae_rmse(g["pred"], g["Xn"] * 2, g["ori_mask"], num_num=g["X"].shape[1])
+    assert abs(mae - float(g["mae"])) < 1e-6 and abs(rmse - float(g["rmse"])) < 1e-6
