@@ -1,0 +1,101 @@
+"""The EM loop around the E-step, as a function (counterpart of main.py:74-262; no CLI, no dataset loading).
+
+M-step = PyTorch (BASELINE.json north_star: "PyTorch-ROCm owns tensors and the M-step"): the reference's training loop
+(main.py:92-152) on `model.Model`, data resident on the device.  E-step = `estep.e_step` on the HIP sampler.  Scoring =
+`prep.masked_errors` on the device.  Files written are the reference's (formats.py): `<ckpt_dir>/<k>/model.pt`,
+`<ckpt_dir>/iter_<k+1>.npy`.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import torch
+
+from . import estep, formats, prep
+from .model import MLPDiffusion, Model
+
+
+def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, batch_size: int = 4096, lr: float = 1e-4,
+           patience: int = 500, generator: torch.Generator | None = None, log=None):
+    """main.py:92-152: a FRESH MLPDiffusion each EM iteration, Adam(lr 1e-4), ReduceLROnPlateau(0.9, 50), shuffled batches of
+    4096, best-epoch-loss checkpoint, early stop after `patience` epochs without improvement.  Returns (model with the best
+    weights loaded, best loss).  `train_data` [N, D] float32 on the training device."""
+    dev = train_data.device
+    n, d = train_data.shape
+    model = Model(denoise_fn=MLPDiffusion(d, hid_dim), hid_dim=d).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.9, patience=50)
+    model.train()
+    best, best_sd, stale = float("inf"), None, 0
+    for epoch in range(max_epochs):
+        perm = torch.randperm(n, device=dev, generator=generator)
+        tot = torch.zeros((), device=dev)
+        for b0 in range(0, n, batch_size):
+            x = train_data[perm[b0:b0 + batch_size]]
+            loss = model(x).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            tot += loss.detach() * x.shape[0]              # accumulated on the device: one host sync per epoch, not per batch
+        cur = float(tot) / n
+        sched.step(cur)
+        if cur < best:
+            best, stale = cur, 0
+            best_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            stale += 1
+            if stale == patience:
+                break
+        if log and epoch % 100 == 0:
+            log(f"  epoch {epoch}: loss {cur:.4f} (best {best:.4f})")
+    model.load_state_dict(best_sd)
+    model.eval()
+    return model, best
+
+
+@dataclass
+class EMResult:
+    mae_in: list = field(default_factory=list)
+    rmse_in: list = field(default_factory=list)
+    mae_out: list = field(default_factory=list)
+    rmse_out: list = field(default_factory=list)
+    train_loss: list = field(default_factory=list)
+    imputed: torch.Tensor | None = None          # last in-sample trial mean, x2 scale (what iter_k.npy holds)
+
+
+def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, max_iter: int = 10, num_trials: int = 20,
+           num_steps: int = 50, device="cuda:0", ckpt_dir: str | None = None, max_epochs: int = 10001, dtype: str | None = None,
+           seed: int = 0, num_num: int | None = None, log=print) -> EMResult:
+    """X, X_test: normalised tables ((x - mean)/std/2, main.py:58,61) holding the TRUE values (used for scoring only, like the
+    reference); masks True = missing.  Under torch.distributed the E-step shards rows over ranks (estep.e_step)."""
+    dev = torch.device(device)
+    X = torch.as_tensor(X).to(dev, torch.float32).contiguous()
+    m_tr = torch.as_tensor(mask_train).to(dev).contiguous()
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    res = EMResult()
+    train_data = (1.0 - m_tr.float()) * X                                     # iteration 0: zero-filled (main.py:84-86)
+    for it in range(max_iter):
+        log(f"EM iteration {it}: M-step on {tuple(train_data.shape)}")
+        model, loss = m_step(train_data, hid_dim, max_epochs=max_epochs, generator=gen, log=log)
+        res.train_loss.append(loss)
+        if ckpt_dir:
+            formats.save_checkpoint(os.path.join(ckpt_dir, str(it), "model.pt"), model)
+        net = model.denoise_fn_D
+        rec = estep.e_step(net, X, m_tr, num_trials, num_steps, dev, seed=seed + 1000 * it, dtype=dtype)       # main.py:156-188
+        rec2 = rec * 2                                                        # main.py:190
+        if ckpt_dir:
+            formats.save_iteration(os.path.join(ckpt_dir, f"iter_{it + 1}.npy"), rec2)
+        mae, rmse = prep.masked_errors(rec2, X * 2, m_tr, num_num)             # main.py:201
+        res.mae_in.append(mae); res.rmse_in.append(rmse)
+        log(f"  in-sample      MAE {mae:.4f} RMSE {rmse:.4f}")
+        if X_test is not None:
+            Xt = torch.as_tensor(X_test).to(dev, torch.float32).contiguous()
+            mt = torch.as_tensor(mask_test).to(dev).contiguous()
+            rec_t = estep.e_step(net, Xt, mt, num_trials, num_steps, dev, seed=seed + 1000 * it + 500, dtype=dtype)   # main.py:208-238
+            mae, rmse = prep.masked_errors(rec_t * 2, Xt * 2, mt, num_num)
+            res.mae_out.append(mae); res.rmse_out.append(rmse)
+            log(f"  out-of-sample  MAE {mae:.4f} RMSE {rmse:.4f}")
+        train_data = rec2 / 2                                                 # next M-step trains on the imputation (main.py:88-90)
+        res.imputed = rec2
+    return res
