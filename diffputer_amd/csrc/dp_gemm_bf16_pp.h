@@ -167,6 +167,19 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         __builtin_amdgcn_s_barrier();                                                                           \
     } while (0)
+#ifdef DP_PP_PHASES                                              /* stamp build: cycles per phase type */
+    unsigned long long ph_acc[4] = {0, 0, 0, 0}, ph_last = 0;
+#define PP_PHASE_MARK(c)                                                                                        \
+    do {                                                                                                        \
+        unsigned long long t_;                                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                            \
+        ph_acc[c] += t_ - ph_last;                                                                              \
+        ph_last = t_;                                                                                           \
+    } while (0)
+#else
+#define PP_PHASE_MARK(c) do { } while (0)
+#endif
+
     // One K-tile (DMA issue kept out of the phase with the 12 fragment reads; B1 read one phase early into
     // the registers q(A1,B0) does not use):
     //   phase   ds_read_b128                 LDS-DMA (half-tiles)         MFMA quadrant    vmcnt after the stage
@@ -185,21 +198,25 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         PP_READ_B(bf0, buf, 0);                                                                                 \
         PP_READ_A(buf, 0);                                                                                      \
         PP_MFMA(0, 0, bf0);                                                                                     \
+        PP_PHASE_MARK(0);                                                                                     \
         /* c1 */                                                                                                \
         if (ST1) stage_a((kt) + 1, 1);                                                                          \
         if (ST2) stage_b((kt) + 2, 1);                                                                          \
         WAIT(1);                                                                                                \
         PP_MFMA(0, 1, bf1);                                                                                     \
+        PP_PHASE_MARK(1);                                                                                     \
         /* c2 */                                                                                                \
         PP_READ_A(buf, 1);                                                                                      \
         if (ST2) stage_a((kt) + 2, 0);                                                                          \
         WAIT(2);                                                                                                \
         PP_MFMA(1, 1, bf1);                                                                                     \
+        PP_PHASE_MARK(2);                                                                                     \
         /* c3 */                                                                                                \
         if (ST1) PP_READ_B(bf1, nbuf, 1);                                                                       \
         if (ST2) stage_b((kt) + 2, 0);                                                                          \
         WAIT(3);                                                                                                \
         PP_MFMA(1, 0, bf0);                                                                                     \
+        PP_PHASE_MARK(3);                                                                                     \
     } while (0)
     // During K-tile 0 of a tile whose prologue was issued ahead of the previous epilogue, that epilogue's NST stores sit
     // behind the prologue DMA in the in-order vmcnt queue.
@@ -248,6 +265,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         DP_LGKMCNT0();
         __builtin_amdgcn_s_barrier();
         PP_STAMP(1);
+#ifdef DP_PP_PHASES
+        ph_last = stamp[1];
+        ph_acc[0] = ph_acc[1] = ph_acc[2] = ph_acc[3] = 0;
+#endif
 
         if (first) PP_TILE(0, true, true, PP_WAIT_MAIN);
         else PP_TILE(0, true, true, PP_WAIT_T0);
@@ -376,6 +397,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         if (g_pp_stamp_buf && round < 16 && (tid & 255) == 0) {                     // wave 0 and wave 4 (one per wave row)
             unsigned long long* d = g_pp_stamp_buf + (((size_t)blockIdx.x * 16 + round) * 2 + (tid >> 8)) * 8;
             for (int k = 0; k < 5; ++k) d[k] = stamp[k];
+#ifdef DP_PP_PHASES
+            for (int k = 0; k < 3; ++k) d[5 + k] = ph_acc[k];     // c3 = K loop - (c0 + c1 + c2)
+#endif
         }
         ++round;
 #endif

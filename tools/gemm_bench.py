@@ -24,6 +24,8 @@ ap.add_argument("--only", default=None)
 ap.add_argument("--act", type=int, default=1)
 ap.add_argument("--shapes", default=None, help="extra shapes as N:K,N:K (replaces the default list)")
 a = ap.parse_args()
+if os.environ.get('DP_DIAG_LIB'):
+    _lib.LIB_PATH = os.environ['DP_DIAG_LIB']                # A/B a diagnostic build on one box
 lib = _lib.load()
 dev = "cuda:0"
 variants = [int(v) for v in a.variants.split(",")]

@@ -51,6 +51,18 @@ run()
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
+if os.environ.get("DP_COLD"):                                       # one launch after an idle second: DVFS headroom
+    import time
+    for pause in (0.05, 0.5, 2.0):
+        time.sleep(pause)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        c = buf.cpu().numpy().reshape(grid, 16, 2, 8).astype(np.float64)
+        clk = np.median((c[:, 7, 0, 3] - c[:, 0, 0, 0]) / (c[:, 7, 0, 4] - c[:, 0, 0, 4]) * 100) if c[0, 0, 0, 4] else float("nan")
+        print(f"after {pause:.2f} s idle: launch {e0.elapsed_time(e1)*1e3:.1f} us = {2.0*a.m*a.n*a.k/e0.elapsed_time(e1)/1e9:.1f} TFLOP/s")
+    for _ in range(a.iters):
+        run()
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
 s = buf.cpu().numpy().reshape(grid, 16, 2, 8).astype(np.float64)
 rounds = int((s[0, :, 0, 0] > 0).sum())
 print(f"M={a.m} N={a.n} K={a.k}: launch {ms*1e3:.1f} us = {2.0*a.m*a.n*a.k/ms/1e9:.1f} TFLOP/s, rounds {rounds}")
@@ -63,6 +75,14 @@ for r in range(rounds):
     start = d[:, 0, 0] - t0_all
     print(f"round {r}: start {np.median(start):9.0f} (min {start.min():9.0f} max {start.max():9.0f}) | prologue wait med {np.median(pro):7.0f} max {pro.max():7.0f} | "
           f"K loop med {np.median(loop):7.0f} min {loop.min():7.0f} max {loop.max():7.0f} | epilogue med {np.median(epi):6.0f} max {epi.max():6.0f}  [cycles]")
+if s[:, :, :, 5].max() > 0:                                             # -DDP_PP_PHASES build: cycles per phase type
+    nk = a.k // 64
+    for row in range(2):
+        d = s[:, 1, row]
+        loop = d[:, 2] - d[:, 1]
+        c = [np.median(d[:, 5 + k]) / nk for k in range(3)]
+        c.append(np.median(loop - d[:, 5] - d[:, 6] - d[:, 7]) / nk)
+        print(f"wave row {row}: cycles per phase c0..c3 = " + " ".join(f"{x:.0f}" for x in c) + f"  (sum {sum(c):.0f}; MFMA-bound would be 512 each)")
 tot_cycles = (s[:, rounds - 1, 0, 3] - s[:, 0, 0, 0])
 tot_real = (s[:, rounds - 1, 0, 4] - s[:, 0, 0, 4])
 print(f"kernel span per WG: med {np.median(tot_cycles):.0f} cycles")
