@@ -65,9 +65,10 @@ def plan_calls(n_rows: int, num_trials: int, max_chains: int):
 
 
 def impute_trials(plan: SamplerPlan, X, mask, num_trials: int, *, seed: int = 0, row_offset: int = 0,
-                  max_chains: int = DEFAULT_MAX_CHAINS, prefilled: bool = False) -> torch.Tensor:
+                  max_chains: int = DEFAULT_MAX_CHAINS, prefilled: bool = False, trial_range=None) -> torch.Tensor:
     """Mean over `num_trials` trials of rec*mask + x_obs*(1-mask) for the rows given (main.py:160-188).
-    X [n, D] float32 in the sampler's scale ((x-mean)/std/2, main.py:58); mask True = missing."""
+    X [n, D] float32 in the sampler's scale ((x-mean)/std/2, main.py:58); mask True = missing.
+    trial_range=(t0, t1): only the global trials t0..t1-1 are run and their SUM is returned (trial sharding)."""
     dev = plan.device
     # pandas-derived tables are often column-major: everything handed to the library must be row-major
     X = torch.as_tensor(X).to(dev, torch.float32).contiguous()
@@ -78,19 +79,26 @@ def impute_trials(plan: SamplerPlan, X, mask, num_trials: int, *, seed: int = 0,
     n = x_obs.shape[0]
     if n == 0:
         return out
-    for r0, r1, t0, t1 in plan_calls(n, num_trials, max_chains):
-        plan.impute_sum(x_obs[r0:r1], m8[r0:r1], t1 - t0, seed=seed, row_offset=row_offset + r0, trial_offset=t0,
+    tb, te = (0, num_trials) if trial_range is None else trial_range
+    if te <= tb:
+        return out
+    for r0, r1, t0, t1 in plan_calls(n, te - tb, max_chains):
+        plan.impute_sum(x_obs[r0:r1], m8[r0:r1], t1 - t0, seed=seed, row_offset=row_offset + r0, trial_offset=tb + t0,
                         out=out[r0:r1], accumulate=t0 > 0)
-    return out / num_trials                                                 # the .mean(0) of main.py:188
+    return out / num_trials if trial_range is None else out                 # the .mean(0) of main.py:188
 
 
 def e_step(net, X, mask, num_trials: int = 20, num_steps: int = 50, device="cuda:0", *, seed: int = 0, dtype=None,
-           n_resample: int = N_RESAMPLE, max_chains: int = DEFAULT_MAX_CHAINS, group=None, gather: bool = True) -> torch.Tensor:
+           n_resample: int = N_RESAMPLE, max_chains: int = DEFAULT_MAX_CHAINS, group=None, gather: bool = True,
+           shard: str = "rows") -> torch.Tensor:
     """Full E-step for one table: returns the trial-mean imputation [N, D] in the sampler's scale
     (the caller multiplies by 2 and saves iter_{k+1}.npy, main.py:190-193).
 
     With torch.distributed initialised, every rank passes the same full X/mask, samples its own
-    row shard and receives the gathered result (gather=False returns only the local shard)."""
+    row shard and receives the gathered result (gather=False returns only the local shard).
+    shard="trials" (few rows, many trials -- news with T = 50): every rank runs all rows for its own
+    contiguous block of trials and the per-rank sums are all-reduced; the trial sum is then grouped per rank, so the
+    result equals the row-sharded one to float32 rounding of that regrouping, not bit for bit."""
     import torch.distributed as dist
 
     distributed = dist.is_available() and dist.is_initialized()
@@ -99,6 +107,14 @@ def e_step(net, X, mask, num_trials: int = 20, num_steps: int = 50, device="cuda
     n = X.shape[0]
     r0, r1 = shard_bounds(n, world, rank)
     plan = plan_for(net, num_steps, device, dtype, n_resample)
+    if shard == "trials":
+        t0, t1 = shard_bounds(num_trials, world, rank)
+        total = impute_trials(plan, X, mask, num_trials, seed=seed, max_chains=max_chains, trial_range=(t0, t1))
+        if world > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        return total / num_trials
+    if shard != "rows":
+        raise ValueError(f"shard must be 'rows' or 'trials', not {shard!r}")
     local = impute_trials(plan, X[r0:r1], mask[r0:r1], num_trials, seed=seed, row_offset=r0, max_chains=max_chains)
     if world == 1 or not gather:
         return local

@@ -143,6 +143,50 @@ def test_gather_rows_world_size_2_gloo(n):
     assert res == [(0, True), (1, True)]
 
 
+class _FakePlan:
+    """Stands in for SamplerPlan on CPU: trial t of global row r "imputes" r + t/64 in every column, so the E-step
+    driver's sharding, call planning, accumulation and collectives can be checked exactly without a GPU."""
+    device = torch.device("cpu")
+
+    def impute_sum(self, x_obs, mask, num_trials, *, seed=0, row_offset=0, trial_offset=0, out=None, accumulate=False):
+        rows = torch.arange(row_offset, row_offset + x_obs.shape[0], dtype=torch.float32)[:, None]
+        add = sum(rows + (trial_offset + t) / 64.0 for t in range(num_trials)).expand_as(out)
+        if accumulate:
+            out += add
+        else:
+            out.copy_(add)
+        return out, None
+
+
+def _estep_worker(rank, world, port, n, d, T, shard, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    estep.plan_for = lambda *a, **k: _FakePlan()
+    X = torch.zeros(n, d)
+    mask = torch.zeros(n, d, dtype=torch.bool)
+    got = estep.e_step(None, X, mask, num_trials=T, device="cpu", max_chains=16, shard=shard)
+    want = (torch.arange(n, dtype=torch.float32)[:, None] + sum(t / 64.0 for t in range(T)) / T).expand(n, d)
+    q.put((rank, bool(torch.allclose(got, want, rtol=1e-6, atol=0)), tuple(got.shape)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["rows", "trials"])
+def test_e_step_world_size_2_gloo(shard):
+    """The N > 1 E-step path on CPU: two gloo ranks, row sharding (all-gather) and trial sharding (all-reduce)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n, d, T = 13, 3, 5
+    procs = [ctx.Process(target=_estep_worker, args=(r, 2, port, n, d, T, shard, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, (n, d)), (1, True, (n, d))]
+
+
 def test_prep_helpers_match_reference():
     """evalmetrics.mean_std / mae_rmse against the reference's mean_std (dataset.py:161-169) and get_eval (:171-206)
     run on 2 048 california rows (tools/make_prep_golden.py)."""
