@@ -141,11 +141,17 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     const int a_rd[2] = {wm * 8192 + foff, (wm * 8192 + foff) ^ 64};                      // + i * 2048 (m-tile i of the half)
     const int b_rd[2] = {2 * PP_HALF + wn * 4096 + foff, (2 * PP_HALF + wn * 4096 + foff) ^ 64};   // + j * 2048 (n-tile j)
 
-#ifdef PP_DIAG_NOREAD                                            /* timing-only diagnostic: operands stay what they were */
+#ifdef PP_DIAG_NOREAD                                            /* timing-only diagnostic: fragments are read during K-tile 0 of a tile and then kept */
 #define PP_READ_A(buf, h)                                                                                       \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[ks][i]))
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) {            \
+        if (diag_read) af[ks][i] = *(const bf16x8*)((buf) + (h) * PP_HALF + a_rd[ks] + i * 2048);               \
+        else asm volatile("" : "+v"(af[ks][i]));                                                                \
+    }
 #define PP_READ_B(dst, buf, h)                                                                                  \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(dst[ks][j]))
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j) {            \
+        if (diag_read) dst[ks][j] = *(const bf16x8*)((buf) + (h) * PP_HALF + b_rd[ks] + j * 2048);              \
+        else asm volatile("" : "+v"(dst[ks][j]));                                                               \
+    }
 #else
 #define PP_READ_A(buf, h)                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)              \
@@ -250,10 +256,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
                     for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bf16x8 af[2][4], bf0[2][2], bf1[2][2];                   // [ks][tile]
 #ifdef PP_DIAG_NOREAD
-        for (int ks = 0; ks < 2; ++ks) {
-            for (int i = 0; i < 4; ++i) af[ks][i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
-            for (int j = 0; j < 2; ++j) { bf0[ks][j] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8}; bf1[ks][j] = (bf16x8){8, 7, 6, 5, 4, 3, 2, 1}; }
-        }
+        bool diag_read = true;
 #endif
 
         // A0(0), B0(0) have landed (this wave's pieces): all but the 4 newer half-tiles (and the epilogue's stores)
@@ -272,6 +275,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
 
         if (first) PP_TILE(0, true, true, PP_WAIT_MAIN);
         else PP_TILE(0, true, true, PP_WAIT_T0);
+#ifdef PP_DIAG_NOREAD
+        diag_read = false;
+#endif
         int kt = 1;
 #pragma clang loop unroll(disable)
         for (; kt < nk - 2; ++kt) PP_TILE(kt, true, true, PP_WAIT_MAIN);
