@@ -447,6 +447,49 @@ def test_errors_are_loud():
     p.close()
 
 
+@pytest.mark.parametrize("d,n,miss", [(7, 1, "all"), (34, 5, "none"), (51, 3, "mcar"), (9, 2, "row"), (65, 4, "mcar")])
+def test_edge_shapes_and_masks(d, n, miss):
+    """Widths that are not multiples of 4 or 64 (the one-cell-per-thread step kernels, zero-padded GEMM operands:
+    adult's 34, news' 51, one column past a tile), one-row tables, and the mask's extremes: nothing observed (the
+    sampler runs unconditionally), nothing missing (the table comes back bit-exactly), one whole row missing.
+    float32 plan against the oracle on replayed noise, every recorded x_t within 1e-3 relative."""
+    import oracle.diffputer_oracle as orc
+    hid, S, R = 64, 4, 3
+    sd = synth.make_weights(d, hid, 300 + d, 2.0)
+    X, mask = synth.make_table(n, d, seed=400 + d)
+    if miss == "all":
+        mask[:] = True
+    elif miss == "none":
+        mask[:] = False
+    elif miss == "row":
+        mask[:] = False
+        mask[1] = True
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    noise = synth.reference_noise(500 + d, synth.n_draws(S, R), (n, d))
+    tr = []
+    want = orc.impute_mask(sd, x_obs, mask, noise, S, R, trace=tr)
+    p = _plan(sd, S, R, "f32")
+    got, trace = p.impute_sum(x_obs, mask, 1, noise=noise, trace=True)
+    t = orc.sigma_schedule(S)
+    k = 0
+    for i in range(S):
+        for _ in range(R if i < S - 1 else 1):
+            rel_check(trace[k, 0].cpu().numpy(), tr[k], floor=1e-2 * max(float(t[i + 1]), 1e-3), what=f"x_t[{k}] d={d} {miss}")
+            k += 1
+    rel_check(got.cpu().numpy(), want * mask + x_obs * (1 - mask), floor=1e-3, what="result")
+    obs = ~mask
+    assert np.array_equal(got.cpu().numpy()[obs], x_obs[obs]), "observed cells must come back bit-exactly"
+    # the bf16 plan takes the same shapes (zero-padded K, ragged N) and agrees to its own, looser bound
+    pb = _plan(sd, S, R, "bf16")
+    gb, _ = pb.impute_sum(x_obs, mask, 1, noise=noise)
+    assert np.array_equal(gb.cpu().numpy()[obs], x_obs[obs])
+    ref = got.cpu().numpy()
+    err = np.abs(gb.cpu().numpy() - ref)
+    assert np.all(err <= np.maximum(1e-1, 4e-2 * np.abs(ref))), f"bf16 max err {err.max():.3e}"
+    p.close()
+    pb.close()
+
+
 # ------------------------------------------------------------------------------------------------ the bench configuration
 def test_full_config_properties():
     """BASELINE configs[4] shape (D = 256, H = 1024, S = 50, R = 20, bf16, proj folded, mid step fused) on a ragged shard:
