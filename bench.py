@@ -42,31 +42,28 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
 
 
 def cpu_baseline(d, hid, S, R, T, rows, budget_note):
-    """The numpy oracle on the host cores: `rows` rows x 1 trial of the same workload."""
-    from oracle import diffputer_oracle as orc                            # the only place bench.py touches oracle/
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    """The CPU port on the host cores: `rows` rows x 1 trial of the same workload, float32, torch CPU operators
+    (what the reference's sampler runs on: `addmm` on torch's BLAS, torch's SiLU), oracle/diffputer_oracle_torch.py."""
+    from oracle import diffputer_oracle_torch as orct                     # the only place bench.py touches oracle/
+    cores = torch.get_num_threads()
     sd = synth.make_weights(d, hid, seed=11, gain=1.0)
     X, mask = synth.make_table(rows, d, seed=12)
     x_obs = (X * (1.0 - mask)).astype(np.float32)
 
     class LazyNoise:                                                      # 3 924 x rows x d floats would not fit; draw on demand
         def __init__(self):
-            self.rng = np.random.Generator(np.random.Philox(13))
+            self.gen = torch.Generator().manual_seed(13)
 
         def __getitem__(self, k):
-            return self.rng.standard_normal((rows, d), dtype=np.float32)
+            return torch.randn((rows, d), generator=self.gen)
 
     t0 = time.perf_counter()
-    orc.impute_mask(sd, x_obs, mask, LazyNoise(), S, R)
+    orct.impute_mask(sd, x_obs, mask, LazyNoise(), S, R)
     dt = time.perf_counter() - t0
     row_trials_per_s = rows / dt
     return {"value": row_trials_per_s / T, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": f"{rows} rows x 1 trial, full S={S}/R={R} schedule, D={d}, H={hid}, numpy float32 oracle "
-                      f"({dt:.1f} s; rows/s = row-trials/s / T={T}){budget_note}",
+            "sample": f"{rows} rows x 1 trial, full S={S}/R={R} schedule, D={d}, H={hid}, float32 port on torch CPU operators "
+                      f"({dt:.1f} s on {cores} threads; rows/s = row-trials/s / T={T}){budget_note}",
             "row_trials_per_s": row_trials_per_s}
 
 
@@ -99,7 +96,7 @@ def main():
     ap.add_argument("--trials", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--max-chains", type=int, default=1 << 16)
-    ap.add_argument("--cpu-rows", type=int, default=512, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
     a = ap.parse_args()

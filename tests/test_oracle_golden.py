@@ -96,6 +96,23 @@ def test_impute_mask_trajectory(name):
     assert np.array_equal(g["out"][obs], g["x_obs"][obs])
 
 
+@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16", "impute_D64_H1024_S10_N32"])
+def test_torch_oracle_trajectory(name):
+    """oracle/diffputer_oracle_torch.py (the restatement bench.py times as the CPU baseline: torch CPU operators, as the
+    reference uses) against the same reference-generated trajectories."""
+    from oracle import diffputer_oracle_torch as orct
+    g = load_golden(name)
+    sd = synth.make_weights(int(g["d_in"]), int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+    stream = g["noise"] if "noise" in g else golden_noise(g)
+    trace = []
+    out = orct.impute_mask(sd, g["x_obs"], g["mask"], stream, int(g["S"]), int(g["R"]), trace)
+    close(out, g["out"], atol=2e-5)
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        close(trace[k], ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    obs = ~g["mask"]
+    assert np.array_equal(out[obs], g["x_obs"][obs])
+
+
 def test_impute_mask_noise_stored_equals_regenerated():
     g = load_golden("impute_D9_H64_S5_N8")
     assert np.array_equal(golden_noise(g), g["noise"])
