@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
+    ap.add_argument("--m-chunk", type=int, default=None, help="rows per wide-layer GEMM launch (dp_tune m_chunk; 0 = whole batch)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +118,8 @@ def main():
     folded = a.dtype == "bf16" and not a.no_fold
     from diffputer_amd import _lib
     _lib.check(_lib.load().dp_tune(b"fold_proj", 0 if a.no_fold else 1), "dp_tune")
+    if a.m_chunk is not None:
+        _lib.check(_lib.load().dp_tune(b"m_chunk", a.m_chunk), "dp_tune")
     # random-init weights of the reference architecture (throughput is weight-independent), synthetic table shard
     sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(d, hid, seed=1, gain=1.0).items()}
     plan = SamplerPlan(sd, num_steps=S, n_resample=R, dtype=a.dtype, device=dev)
@@ -176,7 +179,8 @@ def main():
         "config": {"workload": f"BASELINE configs[4]: synthetic 10M x {d} table, S={S} x R={R} x Heun, T={T} trials, "
                                f"hid={hid}; each step = full E-step of a {a.rows}-row shard per GPU (MCAR 30%, random-init weights)",
                    "rows_per_step_per_gpu": a.rows, "cols": d, "num_steps": S, "n_resample": R, "num_trials": T, "hid": hid,
-                   "chains_per_call": min(a.max_chains, a.rows * T), "parallelism": f"row-shard x{world}, all-gather of trial means"},
+                   "chains_per_call": min(a.max_chains, a.rows * T), "wide_gemm_rows_per_launch": plan.gemm_rows(min(a.max_chains, a.rows * T)),
+                   "parallelism": f"row-shard x{world}, all-gather of trial means"},
         "row_trials_per_s": rows_per_s * T, "denoiser_row_evals_per_s": rows_per_s * T * nfe,
         "whole_path": {"tflops_per_gpu": whole_tflops, "frac_of_mfma_peak": whole_tflops / peak,
                        "flops_per_row": T * nfe * fl_row_eval,
@@ -190,8 +194,9 @@ def main():
         ms, cnt = plan.profile_read()
         chains = min(a.max_chains, a.rows * T)
         Mp = -(-chains // 256) * 256
+        Mc = plan.gemm_rows(chains)                    # rows per launch of the wide layers (the batch runs in chunks)
         N5 = K1
-        layer_flops = [2.0 * Mp * H * K1, 2.0 * Mp * 2 * H * (K1 if folded else H), 2.0 * Mp * 2 * H * 2 * H, 2.0 * Mp * H * 2 * H,
+        layer_flops = [2.0 * Mc * H * K1, 2.0 * Mc * 2 * H * (K1 if folded else H), 2.0 * Mc * 2 * H * 2 * H, 2.0 * Mc * H * 2 * H,
                        2.0 * Mp * N5 * H]
         per = {}
         names = ["gemm_proj", "gemm_mlp0", "gemm_mlp2", "gemm_mlp4", "gemm_mlp6", "step_mid", "step_end", "step_final"]
@@ -206,11 +211,11 @@ def main():
             avg_ms = sum(ms[i] / cnt[i] for i in (1, 2, 3)) / 3.0
             avg_flops = sum(layer_flops[i] for i in (1, 2, 3)) / 3.0
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mp)
+            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mc)
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                   "traffic_source": traffic_src,
                                   "kernel": ("k_gemm_bf16_pp<SiLU,bf16-out> (" + ("proj+mlp.0" if folded else "mlp.0") + ", mlp.2, mlp.4)") if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
-                                  "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mp}
+                                  "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mc}
         # fused step kernel (after the 2nd evaluation): algorithmic bytes per cell = x_hat r/w 8 + d_cur 4 + F 4 + x_obs 4 + mask 1 + u 2
         if cnt[6]:
             cells = chains * d

@@ -81,6 +81,7 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
 // "fold_proj" 1 = evaluate proj and mlp.0 as one Linear (default), 0 = as two GEMMs like the reference's module list
 static int g_gemm_variant = 2;
 static int g_fold_proj = 1;
+static int g_m_chunk = 32768;     // "m_chunk": rows per launch of the wide layers in bf16 plans (0 = whole batch), see eval_F
 static int g_fuse_mid = 1;        // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 
 static int g_num_cus = 0;       // CUs of the current device: the persistent kernel runs one workgroup per CU
@@ -203,29 +204,56 @@ static bool mid_fused(const dp_plan* p) {
 // ---- one denoiser evaluation F(u, level): the Linear layers as GEMMs with fused epilogues (model.py:121-128) ------
 // `level` = row of the b_eff / b01 tables (0 .. n_levels-1 the schedule's levels, n_levels / n_levels+1 scratch).
 // `ev`: NULL, or 7 events of a profiling sample; [0..5] are recorded here, [6] by the caller after its step kernel.
+// Rows per launch of the wide layers for a batch of Mp rows: Mp cut into equal chunks of at most g_m_chunk rows, a
+// multiple of 256.  bf16 plans only (the float32 path keeps one launch per layer).
+static int64_t chunk_rows(const dp_plan* p, int64_t Mp) {
+    if (p->dtype != DP_DTYPE_BF16 || g_m_chunk <= 0 || Mp <= g_m_chunk) return Mp;
+    const int64_t n = ceil_div<int64_t>(Mp, g_m_chunk);
+    return round_up<int64_t>(ceil_div<int64_t>(Mp, n), 256);
+}
+
+// The wide layers run chunk by chunk (proj+mlp.0, mlp.2, mlp.4 of rows [r0, r1), then the next chunk) and mlp.6 once
+// over the whole batch: a chunk's activations (2 x 128 MiB at 32 768 rows, H = 1024) are then still in the 256 MiB
+// Infinity Cache when the next layer reads them, where a 65 536-row layer streams them through HBM; measured 6-8 %
+// off mlp.0 / mlp.2 per row.  Rows are independent, so results do not depend on the chunking.  h3 = mlp.4's output
+// [Mp, H] occupies the first half of actB: rows [0, r1) of it end at byte r1*H, before the h1 rows (2H wide) of every
+// LATER chunk begin (r1*2H), and only over h1 rows of chunks that mlp.2 has already consumed.
 static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t st, hipEvent_t* ev = nullptr, const MidStep* mid = nullptr) {
     const int H = p->hid, dt = p->dtype;
+    const size_t es = p->esize();
     int rc;
-#define DP_EV(i) do { if (ev) DP_HIP(hipEventRecord(ev[i], st)); } while (0)
-    DP_EV(0);
-    if (folded(p)) {
-        // (W0 Wp) u + (W0 b_eff + b0), SiLU: proj + emb + mlp.0 + mlp.1 in one GEMM; slot 0 of the profile stays empty
-        DP_EV(1);
-        if ((rc = gemm(dt, w.u, p->W01, p->b01 + (size_t)level * 2 * H, w.actB, 2 * H, w.Mp, 2 * H, p->K1, 1, 0, st))) return rc;
-    } else {
-        if ((rc = gemm(dt, w.u, p->W[0], p->b_eff + (size_t)level * H, w.actA, H, w.Mp, H, p->K1, 0, 0, st))) return rc;   // proj + emb (no act)
-        DP_EV(1);
-        if ((rc = gemm(dt, w.actA, p->W[1], p->B[1], w.actB, 2 * H, w.Mp, 2 * H, H, 1, 0, st))) return rc;  // mlp.0 + SiLU
+#define DP_EV(i) do { if (ev && last) DP_HIP(hipEventRecord(ev[i], st)); } while (0)
+    const int64_t chunk = chunk_rows(p, w.Mp);
+    // ascending rows (the h3 layout below relies on it); the FIRST chunk takes the remainder, so the last one, which a
+    // profiled evaluation times back to back with mlp.6, is always a full chunk
+    const int64_t first_rows = w.Mp - (ceil_div<int64_t>(w.Mp, chunk) - 1) * chunk;
+    for (int64_t r0 = 0, m = first_rows; r0 < w.Mp; r0 += m, m = chunk) {
+        const bool last = r0 + m == w.Mp;
+        const char* u = (const char*)w.u + (size_t)r0 * p->K1 * es;
+        char* a2 = (char*)w.actA + (size_t)r0 * 2 * H * es;       // rows of a [Mp, 2H] buffer
+        char* b2 = (char*)w.actB + (size_t)r0 * 2 * H * es;
+        char* a1 = (char*)w.actA + (size_t)r0 * H * es;           // rows of a [Mp, H] buffer
+        char* b1 = (char*)w.actB + (size_t)r0 * H * es;
+        DP_EV(0);
+        if (folded(p)) {
+            // (W0 Wp) u + (W0 b_eff + b0), SiLU: proj + emb + mlp.0 + mlp.1 in one GEMM; slot 0 of the profile stays empty
+            DP_EV(1);
+            if ((rc = gemm(dt, u, p->W01, p->b01 + (size_t)level * 2 * H, b2, 2 * H, m, 2 * H, p->K1, 1, 0, st))) return rc;
+        } else {
+            if ((rc = gemm(dt, u, p->W[0], p->b_eff + (size_t)level * H, a1, H, m, H, p->K1, 0, 0, st))) return rc;   // proj + emb (no act)
+            DP_EV(1);
+            if ((rc = gemm(dt, a1, p->W[1], p->B[1], b2, 2 * H, m, 2 * H, H, 1, 0, st))) return rc;  // mlp.0 + SiLU
+        }
+        DP_EV(2);
+        if ((rc = gemm(dt, b2, p->W[2], p->B[2], a2, 2 * H, m, 2 * H, 2 * H, 1, 0, st))) return rc;  // mlp.2 + SiLU
+        DP_EV(3);
+        if ((rc = gemm(dt, a2, p->W[3], p->B[3], b1, H, m, H, 2 * H, 1, 0, st))) return rc;          // mlp.4 + SiLU
+        DP_EV(4);
     }
-    DP_EV(2);
-    if ((rc = gemm(dt, w.actB, p->W[2], p->B[2], w.actA, 2 * H, w.Mp, 2 * H, 2 * H, 1, 0, st))) return rc;  // mlp.2 + SiLU
-    DP_EV(3);
-    if ((rc = gemm(dt, w.actA, p->W[3], p->B[3], w.actB, H, w.Mp, H, 2 * H, 1, 0, st))) return rc;          // mlp.4 + SiLU
-    DP_EV(4);
     if (mid) {                                                                                              // mlp.6 + the mid step
         if ((rc = launch_bf16_pp((const bf16_t*)w.actB, (const bf16_t*)p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st, mid))) return rc;
     } else if ((rc = gemm(dt, w.actB, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;   // mlp.6 -> f32
-    DP_EV(5);
+    if (ev) DP_HIP(hipEventRecord(ev[5], st));
 #undef DP_EV
     return DP_OK;
 }
@@ -641,6 +669,11 @@ int dp_debug_stamps(void* buf) {
 }
 #endif
 
+int64_t dp_plan_gemm_rows(const dp_plan* plan, int64_t n_chains) {
+    if (!plan || n_chains <= 0) return 0;
+    return chunk_rows(plan, round_up<int64_t>(n_chains, 256));
+}
+
 int dp_tune(const char* key, int value) {
     if (!key) return fail(DP_EINVAL, "key is NULL");
     if (!strcmp(key, "gemm_variant")) {
@@ -651,6 +684,11 @@ int dp_tune(const char* key, int value) {
     if (!strcmp(key, "fuse_mid")) {
         if (value < 0 || value > 1) return fail(DP_EINVAL, "fuse_mid must be 0 or 1");
         g_fuse_mid = value;
+        return DP_OK;
+    }
+    if (!strcmp(key, "m_chunk")) {
+        if (value < 0 || value % 256) return fail(DP_EINVAL, "m_chunk must be 0 (off) or a positive multiple of 256");
+        g_m_chunk = value;
         return DP_OK;
     }
     if (!strcmp(key, "fold_proj")) {

@@ -133,6 +133,10 @@ class SamplerPlan:
             _lib.check(self.lib.dp_plan_profile_read(self._h, ms, cnt), "dp_plan_profile_read")
         return list(ms), list(cnt)
 
+    def gemm_rows(self, n_chains: int) -> int:
+        """Rows per launch of the wide-layer GEMMs for a call of `n_chains` chains (dp_tune "m_chunk")."""
+        return int(self.lib.dp_plan_gemm_rows(self._h, int(n_chains)))
+
     # -- the sampler ---------------------------------------------------------------------------------------
     def _prep(self, x_obs, mask):
         x = torch.as_tensor(x_obs).to(self.device, torch.float32).contiguous()

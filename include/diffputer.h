@@ -143,6 +143,10 @@ int dp_plan_embedding(const dp_plan* plan, float* emb_out);
  * the first evaluation, 6 = step kernel after the second evaluation, 7 = final-level step kernel.
  */
 int dp_plan_profile(dp_plan* plan, int stride);
+/* Rows per launch of the wide-layer GEMMs (proj/mlp.0, mlp.2, mlp.4) for a call of n_chains chains: the batch is cut
+ * into equal chunks of at most "m_chunk" rows (dp_tune) in bf16 plans; mlp.6 and the step kernels take the whole batch.
+ * With chunking on, profile slots 0..3 time the launches of ONE chunk.  0 on error. */
+int64_t dp_plan_gemm_rows(const dp_plan* plan, int64_t n_chains);
 int dp_plan_profile_read(dp_plan* plan, double ms_sum[8], int count[8]);
 
 /*
@@ -161,6 +165,9 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
  *   "fold_proj"     1 (default) = in DP_DTYPE_BF16 plans proj and mlp.0 run as ONE Linear, (W0 Wp) u + (W0 (proj.bias + emb) + b0): no
  *                   activation separates them (model.py:126-128), so this is the same function with one rounding
  *                   of h0 fewer; 0 = two GEMMs as in the reference's module list.  Read at every evaluation.
+ *   "m_chunk"       rows per launch of the wide layers in bf16 plans (default 32768; 0 = the whole batch in one launch):
+ *                   proj+mlp.0, mlp.2, mlp.4 run chunk after chunk so that a chunk's activations stay in the Infinity
+ *                   Cache between layers; rows are independent, results do not change.
  *   "fuse_mid"      1 (default) = for bf16 plans with d_in = 256 the arithmetic after a Heun iteration's first evaluation
  *                   (diffusion_utils.py:100-101) runs in the epilogue of the mlp.6 GEMM instead of a kernel of its own;
  *                   bit-identical results.

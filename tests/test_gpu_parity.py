@@ -330,6 +330,33 @@ def _torch_net(g):
     return model.denoise_fn_D
 
 
+@pytest.mark.parametrize("d,hid", [(256, 256), (9, 64)])
+def test_chunked_wide_layers_bit_identical(d, hid, fold):
+    """dp_tune m_chunk: the wide layers run chunk by chunk (Infinity-Cache residency of the activations); rows are
+    independent, so any chunking must give the bits of the single-launch form -- ragged last chunk, fused mid step
+    (d = 256) and folded / unfolded proj included."""
+    from diffputer_amd import _lib
+    lib = _lib.load()
+    S, R, n, T = 4, 3, 433, 3                                         # 1299 chains -> Mp = 1536
+    sd = synth.make_weights(d, hid, 93, 1.5)
+    X, mask = synth.make_table(n, d, seed=94)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    res = {}
+    try:
+        for chunk in (0, 256, 1024, 32768):
+            _lib.check(lib.dp_tune(b"m_chunk", chunk), "dp_tune")
+            p = _plan(sd, S, R, "bf16")
+            assert p.gemm_rows(n * T) == {0: 1536, 256: 256, 1024: 768, 32768: 1536}[chunk]
+            res[chunk], _ = p.impute_sum(x_obs, mask, T, seed=3)
+            p.close()
+    finally:
+        _lib.check(lib.dp_tune(b"m_chunk", 32768), "dp_tune")
+    for chunk in (256, 1024, 32768):
+        assert torch.equal(res[chunk], res[0]), f"m_chunk={chunk} changes the result"
+    with pytest.raises(_lib.DiffputerError):
+        _lib.check(lib.dp_tune(b"m_chunk", 100), "dp_tune")
+
+
 def test_unconditional_sample_golden():
     """`sample` (diffusion_utils.py:70-88) with the reference's draws replayed."""
     from diffputer_amd import diffusion_utils as du
