@@ -204,36 +204,39 @@ static bool mid_fused(const dp_plan* p) {
 // ---- one denoiser evaluation F(u, level): the Linear layers as GEMMs with fused epilogues (model.py:121-128) ------
 // `level` = row of the b_eff / b01 tables (0 .. n_levels-1 the schedule's levels, n_levels / n_levels+1 scratch).
 // `ev`: NULL, or 7 events of a profiling sample; [0..5] are recorded here, [6] by the caller after its step kernel.
-// Rows per launch of the wide layers for a batch of Mp rows: Mp cut into equal chunks of at most g_m_chunk rows, a
-// multiple of 256.  bf16 plans only (the float32 path keeps one launch per layer).
+// Rows per launch of the wide layers for a batch of Mp rows: at most g_m_chunk and at most Mp/2 (eval_F's buffer layout
+// needs that), a multiple of 256; a remainder, if any, forms a smaller first chunk.  bf16 plans only (the float32 path
+// keeps one launch per layer).
 static int64_t chunk_rows(const dp_plan* p, int64_t Mp) {
     if (p->dtype != DP_DTYPE_BF16 || g_m_chunk <= 0 || Mp <= g_m_chunk) return Mp;
-    const int64_t n = ceil_div<int64_t>(Mp, g_m_chunk);
-    return round_up<int64_t>(ceil_div<int64_t>(Mp, n), 256);
+    const int64_t n = ceil_div<int64_t>(Mp, g_m_chunk);           // >= 2, and Mp / n > g_m_chunk / 2 >= 128
+    return std::max<int64_t>(256, Mp / n / 256 * 256);
 }
 
 // The wide layers run chunk by chunk (proj+mlp.0, mlp.2, mlp.4 of rows [r0, r1), then the next chunk) and mlp.6 once
 // over the whole batch: a chunk's activations (2 x 128 MiB at 32 768 rows, H = 1024) are then still in the 256 MiB
 // Infinity Cache when the next layer reads them, where a 65 536-row layer streams them through HBM; measured 6-8 %
-// off mlp.0 / mlp.2 per row.  Rows are independent, so results do not depend on the chunking.  h3 = mlp.4's output
-// [Mp, H] occupies the first half of actB: rows [0, r1) of it end at byte r1*H, before the h1 rows (2H wide) of every
-// LATER chunk begin (r1*2H), and only over h1 rows of chunks that mlp.2 has already consumed.
+// off mlp.0 / mlp.2 per row.  Rows are independent, so results do not depend on the chunking.  Every chunk writes its
+// h1 / h2 to the START of actB / actA (the same, cache-resident addresses each time; chunk <= Mp/2 rows of width 2H fit
+// the first half); h3 = mlp.4's output [Mp, H] is the second half of actB (with a single chunk h1 spans all of actB,
+// but it is dead when mlp.4 writes h3).
 static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t st, hipEvent_t* ev = nullptr, const MidStep* mid = nullptr) {
     const int H = p->hid, dt = p->dtype;
     const size_t es = p->esize();
     int rc;
 #define DP_EV(i) do { if (ev && last) DP_HIP(hipEventRecord(ev[i], st)); } while (0)
     const int64_t chunk = chunk_rows(p, w.Mp);
+    char* const h3 = (char*)w.actB + (size_t)w.Mp * H * es;       // second half of actB
     // ascending rows (the h3 layout below relies on it); the FIRST chunk takes the remainder, so the last one, which a
     // profiled evaluation times back to back with mlp.6, is always a full chunk
     const int64_t first_rows = w.Mp - (ceil_div<int64_t>(w.Mp, chunk) - 1) * chunk;
     for (int64_t r0 = 0, m = first_rows; r0 < w.Mp; r0 += m, m = chunk) {
         const bool last = r0 + m == w.Mp;
         const char* u = (const char*)w.u + (size_t)r0 * p->K1 * es;
-        char* a2 = (char*)w.actA + (size_t)r0 * 2 * H * es;       // rows of a [Mp, 2H] buffer
-        char* b2 = (char*)w.actB + (size_t)r0 * 2 * H * es;
-        char* a1 = (char*)w.actA + (size_t)r0 * H * es;           // rows of a [Mp, H] buffer
-        char* b1 = (char*)w.actB + (size_t)r0 * H * es;
+        char* a2 = (char*)w.actA;                                 // h2 [m, 2H] (and proj's output [m, H] before it): the SAME
+        char* b2 = (char*)w.actB;                                 // addresses for every chunk, h1 [m, 2H] likewise
+        char* a1 = (char*)w.actA;
+        char* b1 = h3 + (size_t)r0 * H * es;                      // this chunk's rows of h3 [Mp, H]
         DP_EV(0);
         if (folded(p)) {
             // (W0 Wp) u + (W0 b_eff + b0), SiLU: proj + emb + mlp.0 + mlp.1 in one GEMM; slot 0 of the profile stays empty
@@ -251,8 +254,8 @@ static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t s
         DP_EV(4);
     }
     if (mid) {                                                                                              // mlp.6 + the mid step
-        if ((rc = launch_bf16_pp((const bf16_t*)w.actB, (const bf16_t*)p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st, mid))) return rc;
-    } else if ((rc = gemm(dt, w.actB, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;   // mlp.6 -> f32
+        if ((rc = launch_bf16_pp((const bf16_t*)h3, (const bf16_t*)p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st, mid))) return rc;
+    } else if ((rc = gemm(dt, h3, p->W[4], p->B[4], w.F, p->N5, w.Mp, p->N5, H, 0, 1, st))) return rc;   // mlp.6 -> f32
     if (ev) DP_HIP(hipEventRecord(ev[5], st));
 #undef DP_EV
     return DP_OK;
