@@ -19,7 +19,7 @@ namespace dp {
 thread_local std::string g_err;
 
 // ---- host-side float32 scalar algebra, in the reference's operation order -------------------------------------
-// (this TU is compiled with -ffp-contract=off for host code; x86-64 baseline has no fma anyway)
+// (host code targets baseline x86-64, which has no fused multiply-add: nothing here can be contracted)
 struct Coef { float c_skip, c_out, c_in, c_noise; };
 static Coef precond_coef(float s) {                       // model.py:155-158 with sigma_data = 0.5 (model.py:137)
     const float sd2 = 0.25f;
@@ -84,7 +84,13 @@ static int g_fold_proj = 1;
 static int g_m_chunk = 32768;     // "m_chunk": rows per launch of the wide layers in bf16 plans (0 = whole batch), see eval_F
 static int g_fuse_mid = 1;        // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 
-static int g_num_cus = 0;       // CUs of the current device: the persistent kernel runs one workgroup per CU
+// Per-device launch state (a process normally drives one GPU, but nothing here may assume it): CU count for the
+// persistent kernel's grid, and which kernels already carry the dynamic-LDS attribute on which device.
+static int g_num_cus[64] = {0};
+static int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 ? dev : -1;
+}
 
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
                           int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr) {
@@ -92,23 +98,24 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     const int64_t nwg64 = (M / PP_BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
-    if (!g_num_cus) {
-        int dev = 0;
+    const int dev = current_device();
+    if (dev < 0) return fail(DP_EHIP, "hipGetDevice failed or device index >= 64");
+    if (!g_num_cus[dev]) {
         hipDeviceProp_t prop;
-        DP_HIP(hipGetDevice(&dev));
         DP_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus = prop.multiProcessorCount;
+        g_num_cus[dev] = prop.multiProcessorCount;
     }
+    const int num_cus = g_num_cus[dev];
     const MidStep ms = mid ? *mid : MidStep{};
 #define DP_GO(ACT, EP)                                                                                              \
     do {                                                                                                            \
         auto kern = k_gemm_bf16_pp<ACT, EP>;                                                                        \
-        static bool attr_done = false;                                                                              \
-        if (!attr_done) {                                                                                           \
+        static uint64_t attr_done = 0;                                                                              \
+        if (!(attr_done >> dev & 1)) {                                                                              \
             DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL)); \
-            attr_done = true;                                                                                       \
+            attr_done |= (uint64_t)1 << dev;                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL(kern, dim3(std::min(nwg, g_num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms); \
+        hipLaunchKernelGGL(kern, dim3(std::min(nwg, num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms); \
     } while (0)
     if (mid) {
         if (act || N != 256) return fail(DP_EINVAL, "the fused mid-step epilogue needs N = 256 and no activation");
@@ -130,13 +137,15 @@ static int launch_bf16_cfg(const bf16_t* A, const bf16_t* W, const float* bias, 
     const int64_t nwg64 = (M / BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
+    const int dev = current_device();
+    if (dev < 0) return fail(DP_EHIP, "hipGetDevice failed or device index >= 64");
 #define DP_GO(ACT, OF)                                                                                              \
     do {                                                                                                            \
         auto kern = k_gemm_bf16<BM, BN, WM, WN, ACT, OF>;                                                           \
-        static bool attr_done = false;                                                                              \
-        if (!attr_done) {                                                                                           \
+        static uint64_t attr_done = 0;                                                                              \
+        if (!(attr_done >> dev & 1)) {                                                                              \
             DP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));        \
-            attr_done = true;                                                                                       \
+            attr_done |= (uint64_t)1 << dev;                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(WM* WN * 64), LDS, st, A, W, bias, out, ldo, K, nbn, nwg);         \
     } while (0)
