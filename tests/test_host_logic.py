@@ -197,3 +197,28 @@ def test_prep_helpers_match_reference():
     assert np.allclose(mean, g["mean"], rtol=1e-6, atol=0) and np.allclose(std, g["std"], rtol=1e-6, atol=0)
     mae, rmse = mae_rmse(g["pred"], g["Xn"] * 2, g["ori_mask"], num_num=g["X"].shape[1])
     assert abs(mae - float(g["mae"])) < 1e-6 and abs(rmse - float(g["rmse"])) < 1e-6
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The last bench line committed under profiles/ (written by `python bench.py` on the GPU box) carries every key the
+    driver and the judge read, with the roofline arithmetic consistent."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(p for p in glob.glob(os.path.join(root, "profiles", "r*_bench.json")) if "rocprof" not in p)
+    assert paths, "no bench line under profiles/"
+    r = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["unit"] == "rows/s" and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["dtype"] == "bf16" and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["achieved"] - rf["alg_flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * rf["achieved"]
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "rows/s" and cb["sample"]
+    rows = r["config"]["rows_per_step_per_gpu"] * r["n_gpus"]
+    assert abs(r["value"] - rows / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
