@@ -430,6 +430,25 @@ def test_column_major_table_and_out_validation():
     p.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_call_planning_does_not_change_results(dtype):
+    """estep.impute_trials cuts rows x trials into dp_impute calls of at most max_chains chains (estep.plan_calls): row
+    chunks, trial batches, or both.  Chains are independent and the trial sum is accumulated in trial order, so the
+    trial mean must come out bit for bit whatever the cut."""
+    from diffputer_amd import estep
+    d, hid, S, R, n, T = 12, 64, 4, 3, 333, 5
+    sd = synth.make_weights(d, hid, 61, 1.5)
+    X, mask = synth.make_table(n, d, seed=62)
+    p = _plan(sd, S, R, dtype)
+    whole = estep.impute_trials(p, X, mask, T, seed=21)                       # one call: 1665 chains
+    for mc in (1000, 400, 333, 100, 7):                                       # trial batches; rows x 1 trial; row chunks
+        cut = estep.impute_trials(p, X, mask, T, seed=21, max_chains=mc)
+        assert torch.equal(cut, whole), f"max_chains={mc} changes the result"
+    off = estep.impute_trials(p, X[100:], mask[100:], T, seed=21, row_offset=100, max_chains=256)
+    assert torch.equal(off, whole[100:])
+    p.close()
+
+
 def test_drop_in_api_matches_plan():
     """impute_mask / sample_step with the reference's signatures, fed a torch Model like main.py:170-180."""
     from diffputer_amd import diffusion_utils as du
