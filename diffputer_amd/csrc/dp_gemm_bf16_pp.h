@@ -352,7 +352,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 c = acc[ha][i][hb][j];
                             float v0 = c[0] + bv[hb][j].x, v1 = c[1] + bv[hb][j].y, v2 = c[2] + bv[hb][j].z, v3 = c[3] + bv[hb][j].w;
-                            if (ACT) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                            if (ACT) { silu_fast2(v0, v1); silu_fast2(v2, v3); }
                             *(float4*)(orow + (size_t)(ha * 64 + i * 16) * ldo + hb * 32 + j * 16) = make_float4(v0, v1, v2, v3);
                         }
         } else {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
                             for (int j = 0; j < 2; ++j) {
                                 const f32x4 c = acc[ha][ip * 2 + ii][hb][j];
                                 float v0 = c[0] + bv[hb][j].x, v1 = c[1] + bv[hb][j].y, v2 = c[2] + bv[hb][j].z, v3 = c[3] + bv[hb][j].w;
-                                if (ACT) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                                if (ACT) { silu_fast2(v0, v1); silu_fast2(v2, v3); }
                                 const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                                 const unsigned addr = wa ^ ((hb * 4 + j * 2) << 4);
                                 if (ii == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pk) : "memory");

@@ -58,6 +58,19 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(floa
 
 // SiLU for the GEMM epilogues: x * sigmoid(x) = x / (1 + e^-x)   (model.py:106,108,110)
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// Two at a time: the scale, the +1 and the final product as packed-f32 instructions (same operations, same bits as
+// silu_fast; the transcendentals stay one per element).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void silu_fast2(float& a, float& b) {
+    const f32x2_t x = {a, b};
+    const f32x2_t t = x * (f32x2_t){-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const f32x2_t d = e + (f32x2_t){1.0f, 1.0f};
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2_t y = x * r;
+    a = y.x;
+    b = y.y;
+}
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
 
 }  // namespace dp
