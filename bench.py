@@ -71,7 +71,7 @@ def pmc_traffic(kernel: str, rows_per_launch: int):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE passes of their own, corrected as MI355X_MICROARCH.md §HBM prescribes; tools/pmc_summary.py).  Counters
     cannot be read inside a timed run, so this is the last measurement on file, valid for the same rows per launch."""
-    path = os.path.join(REPO, "PMC_TRAFFIC.json")     # = profiles/r1_v3_pmc_summary.json (profiles/ does not travel to the GPU box)
+    path = os.path.join(REPO, "PMC_TRAFFIC.json")     # = the newest profiles/r*_pmc_summary.json (profiles/ does not travel to the GPU box)
     try:
         with open(path) as f:
             d = json.load(f)
