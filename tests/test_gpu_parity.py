@@ -398,6 +398,12 @@ def test_device_prep_and_scoring_golden():
     mae, rmse = prep.masked_errors(torch.from_numpy(g["pred"]).to(DEV), torch.from_numpy(g["Xn"]).to(DEV) * 2,
                                    torch.from_numpy(g["ori_mask"]).to(DEV), num_num=X.shape[1])      # mask one column wider
     assert abs(mae - float(g["mae"])) < 1e-6 and abs(rmse - float(g["rmse"])) < 1e-6
+    # get_eval's news quirk (dataset.py:194-197): a row left out of the score = np.delete on pred, truth and mask
+    from diffputer_amd.evalmetrics import mae_rmse
+    want = mae_rmse(g["pred"], g["Xn"] * 2, g["ori_mask"], num_num=X.shape[1], drop_rows=[5, 77])
+    got = prep.masked_errors(torch.from_numpy(g["pred"]).to(DEV), torch.from_numpy(g["Xn"]).to(DEV) * 2,
+                             torch.from_numpy(g["ori_mask"]).to(DEV), num_num=X.shape[1], drop_rows=[5, 77])
+    assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-6 and abs(got[0] - mae) > 0
     # a column with no observed cell: count 1 like the reference (dataset.py:164) -> mean 0, std 0
     m2 = m.clone(); m2[:, 3] = True
     mean2, std2 = prep.masked_mean_std(X, m2)
