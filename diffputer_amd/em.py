@@ -66,9 +66,10 @@ class EMResult:
 
 def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, max_iter: int = 10, num_trials: int = 20,
            num_steps: int = 50, device="cuda:0", ckpt_dir: str | None = None, max_epochs: int = 10001, dtype: str | None = None,
-           seed: int = 0, num_num: int | None = None, log=print) -> EMResult:
+           seed: int = 0, num_num: int | None = None, oos_drop_rows=None, log=print) -> EMResult:
     """X, X_test: normalised tables ((x - mean)/std/2, main.py:58,61) holding the TRUE values (used for scoring only, like the
-    reference); masks True = missing.  Under torch.distributed the E-step shards rows over ranks (estep.e_step)."""
+    reference); masks True = missing.  Under torch.distributed the E-step shards rows over ranks (estep.e_step).
+    `oos_drop_rows`: rows of the test table left out of its score (news: [6265], dataset.py:194-197)."""
     dev = torch.device(device)
     X = torch.as_tensor(X).to(dev, torch.float32).contiguous()
     m_tr = torch.as_tensor(mask_train).to(dev).contiguous()
@@ -93,7 +94,7 @@ def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, m
             Xt = torch.as_tensor(X_test).to(dev, torch.float32).contiguous()
             mt = torch.as_tensor(mask_test).to(dev).contiguous()
             rec_t = estep.e_step(net, Xt, mt, num_trials, num_steps, dev, seed=seed + 1000 * it + 500, dtype=dtype)   # main.py:208-238
-            mae, rmse = prep.masked_errors(rec_t * 2, Xt * 2, mt, num_num)
+            mae, rmse = prep.masked_errors(rec_t * 2, Xt * 2, mt, num_num, drop_rows=oos_drop_rows)
             res.mae_out.append(mae); res.rmse_out.append(rmse)
             log(f"  out-of-sample  MAE {mae:.4f} RMSE {rmse:.4f}")
         train_data = rec2 / 2                                                 # next M-step trains on the imputation (main.py:88-90)
