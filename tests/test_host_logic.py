@@ -224,3 +224,33 @@ def test_committed_bench_line_keeps_the_contract():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "rows/s" and cb["sample"]
     rows = r["config"]["rows_per_step_per_gpu"] * r["n_gpus"]
     assert abs(r["value"] - rows / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+
+
+def test_mixed_table_layout():
+    """layout.py against the rules of dataset.py:80-82 (digits = '0{n}b' of the category index, MSB first) and :140-157
+    (a categorical column's mask bit tiled over its digits), spelled out the slow way."""
+    from diffputer_amd import layout
+    rng = np.random.default_rng(5)
+    n_cat = [9, 16, 7, 2, 42, 1]                                     # adult's column sizes among them (SURVEY.md §8d)
+    assert [layout.bits_for(n) for n in n_cat] == [4, 4, 3, 1, 6, 0]
+    N, k = 50, 3
+    num = rng.standard_normal((N, k)).astype(np.float32)
+    cat = np.stack([rng.integers(0, n, N) for n in n_cat], axis=1)
+    X, bins = layout.encode_table(num, cat, n_cat)
+    assert X.dtype == np.float32 and X.shape == (N, k + 18) and list(bins) == [4, 4, 3, 1, 6, 0]
+    for r in range(N):
+        want = "".join(format(int(cat[r, j]), f"0{b}b") if b else "" for j, b in enumerate(bins))
+        assert "".join(str(int(v)) for v in X[r, k:]) == want
+    assert np.array_equal(X[:, :k], num)
+    mask = rng.random((N, k + len(n_cat))) < 0.3
+    ext = layout.extend_mask(mask, k, bins)
+    assert ext.shape == X.shape and np.array_equal(ext[:, :k], mask[:, :k])
+    o = k
+    for j, b in enumerate(bins):
+        for d in range(b):
+            assert np.array_equal(ext[:, o + d], mask[:, k + j])
+        o += b
+    noisy = X[:, k:] + rng.uniform(-0.4, 0.4, X[:, k:].shape)         # an imputation near the digits decodes to the category
+    assert np.array_equal(layout.decode_bits(noisy, bins), cat)
+    with pytest.raises(ValueError):
+        layout.encode_bits(np.array([16]), 4)
