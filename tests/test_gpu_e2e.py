@@ -139,3 +139,35 @@ def test_em_loop_and_wire_formats(tmp_path):
     assert np.allclose(it2[~mask], (X * 2)[~mask], rtol=1e-5, atol=1e-6)           # observed cells pass through, x2 scale
     assert np.allclose(formats.load_iteration(str(tmp_path / "iter_2.npy")), it2 / 2)
     assert np.allclose(res.imputed.cpu().numpy(), it2)
+
+
+def test_em_iteration_on_a_mixed_table():
+    """BASELINE configs[1] in miniature: an adult-shaped MIXED table (6 numeric columns + 8 categorical ones of
+    9/16/7/15/6/5/2/42 categories = 28 binary digits, D = 34; layout.py = dataset.py:70-157), normalised on the device
+    with the observed-cell statistics (prep = dataset.mean_std + main.py:55-64), one EM iteration.  The categorical columns
+    are functions of the numeric latent, so a working imputer recovers most masked categories from the observed cells."""
+    from diffputer_amd import em, layout, prep
+    rng = np.random.default_rng(41)
+    N, n_cat = 4000, [9, 16, 7, 15, 6, 5, 2, 42]
+    z = rng.standard_normal((N, 2)).astype(np.float32)
+    num = (z @ rng.standard_normal((2, 6)).astype(np.float32) + 0.1 * rng.standard_normal((N, 6))).astype(np.float32)
+    score = z @ rng.standard_normal((2, len(n_cat))).astype(np.float32)
+    cat = np.stack([np.clip(((score[:, j] + 2.5) / 5.0 * n).astype(np.int64), 0, n - 1) for j, n in enumerate(n_cat)], axis=1)
+    X, bins = layout.encode_table(num, cat, n_cat)
+    assert X.shape == (N, 34)
+    mask0 = rng.random((N, 6 + len(n_cat))) < 0.3                       # over the ORIGINAL columns
+    mask = layout.extend_mask(mask0, 6, bins)
+    Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(mask).to(DEV)
+    mean, std = prep.masked_mean_std(Xd, md)
+    Xn = prep.normalize(Xd, mean, std)
+    res = em.run_em(Xn, md, hid_dim=128, max_iter=1, num_trials=4, num_steps=10, device=DEV, max_epochs=200, seed=5,
+                    num_num=6, log=lambda *_: None)
+    zero_mae, _ = prep.masked_errors(torch.zeros_like(Xn), Xn * 2, md, num_num=6)
+    assert res.mae_in[0] < 0.8 * zero_mae, (res.mae_in, zero_mae)      # numeric columns: get_eval's score
+    rec = res.imputed / 2 * 2 * std + mean                              # main.py:196-199: back to the data scale
+    got = layout.decode_bits(rec[:, 6:].cpu().numpy(), bins)
+    miss = mask0[:, 6:]
+    acc = float((got[miss] == cat[miss]).mean())
+    base = float(np.mean([np.bincount(cat[:, j]).max() / N for j in range(len(n_cat))]))
+    assert np.array_equal(got[~miss], cat[~miss])                       # observed categories pass through exactly
+    assert acc > base + 0.1, (acc, base)                                # masked ones beat the majority-class guess
