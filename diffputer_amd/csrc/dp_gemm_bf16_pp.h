@@ -316,6 +316,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         if (EPI == EPI_MID) {
             const int64_t row0 = om + (elane & 15);
             const int col0 = on + (elane >> 4) * 4;
+            const float inv_t_hat = 1.0f / ms.t_hat;
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -330,10 +331,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
                                 const f32x4 c = acc[ha][i][hb][j];
                                 const float4 xh = *(const float4*)(ms.x_hat + m * 256 + col);
                                 float4 d, u;
-                                mid_step_cell(xh.x, c[0] + bv[hb][j].x, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.x, u.x);
-                                mid_step_cell(xh.y, c[1] + bv[hb][j].y, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.y, u.y);
-                                mid_step_cell(xh.z, c[2] + bv[hb][j].z, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.z, u.z);
-                                mid_step_cell(xh.w, c[3] + bv[hb][j].w, ms.c_skip, ms.c_out, ms.t_hat, ms.h, ms.c_in_next, d.w, u.w);
+                                mid_step_cell(xh.x, c[0] + bv[hb][j].x, ms.c_skip, ms.c_out, inv_t_hat, ms.h, ms.c_in_next, d.x, u.x);
+                                mid_step_cell(xh.y, c[1] + bv[hb][j].y, ms.c_skip, ms.c_out, inv_t_hat, ms.h, ms.c_in_next, d.y, u.y);
+                                mid_step_cell(xh.z, c[2] + bv[hb][j].z, ms.c_skip, ms.c_out, inv_t_hat, ms.h, ms.c_in_next, d.z, u.z);
+                                mid_step_cell(xh.w, c[3] + bv[hb][j].w, ms.c_skip, ms.c_out, inv_t_hat, ms.h, ms.c_in_next, d.w, u.w);
                                 *(float4*)(ms.d_cur + m * 256 + col) = d;
                                 *(uint2*)(ms.u + m * ms.ldu + col) = make_uint2(pack_bf16x2(u.x, u.y), pack_bf16x2(u.z, u.w));
                             }
