@@ -99,15 +99,23 @@ __global__ __launch_bounds__(256) void k_step_init(StepCommon c, float t0, float
         const int64_t e = ev * V;
         Cell k = cell_of(c, e);
         VecF<V> xh, uu;
+        float g0[4], gc[4];                                  // V = 4: the group's x_T and churn draws, one block each
+        if (V == 4 && !c.noise) {
+            noise_group4(c.seed, c.row_offset + k.row, c.trial_offset + k.tl, k.col, DP_PHILOX_INIT_BLOCK, 0, g0);
+            noise_group4(c.seed, c.row_offset + k.row, c.trial_offset + k.tl, k.col, DP_PHILOX_INIT_BLOCK, 2, gc);
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             float z0, zc;
             if (c.noise) {
                 z0 = draw(c, k, 0);
                 zc = draw(c, k, 3);                      // iteration 0: draws 1 n_curr, 2 n_prev, 3 churn, 4 n
+            } else if (V == 4) {
+                z0 = g0[v];
+                zc = gc[v];
             } else {
-                float a, b;
-                philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), DP_PHILOX_INIT_BLOCK, z0, a, zc, b);
+                z0 = noise_cell(c.seed, c.row_offset + k.row, c.trial_offset + k.tl, k.col, DP_PHILOX_INIT_BLOCK, 0);
+                zc = noise_cell(c.seed, c.row_offset + k.row, c.trial_offset + k.tl, k.col, DP_PHILOX_INIT_BLOCK, 2);
             }
             const float x_t = z0 * t0;
             xh.v[v] = x_t + churn0 * zc;
@@ -167,17 +175,32 @@ __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_
         const VecF<V> xhv = ldf<V>(c.x_hat + e), dv = ldf<V>(c.d_cur + e), Fv = ldf<V>(c.F + k.m * c.ldF + k.col);
         const VecF<V> xov = ldf<V>(c.x_obs + oc), mkv = ldmask<V>(c.mask + oc);
         VecF<V> xt, xh2, uu;
+        float gp[4], gr[4], gc[4];                           // V = 4: one block per kind for the thread's column group
+        if (V == 4 && !c.noise) {
+            const uint64_t grow = c.row_offset + k.row;
+            const int gt = c.trial_offset + k.tl;
+            noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 0, gp);
+            if (add_renoise) noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 1, gr);
+            noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 2, gc);
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            float z_prev, z_re, z_churn;
+            float z_prev, z_re = 0.f, z_churn;
             if (c.noise) {
                 const int64_t base = 1 + 4 * (int64_t)it;
                 z_prev = draw(c, k, base + 1);
                 z_re = add_renoise ? draw(c, k, base + 3) : 0.f;
                 z_churn = draw(c, k, base + 4 + 2);      // churn draw of iteration it+1
+            } else if (V == 4) {
+                z_prev = gp[v];
+                if (add_renoise) z_re = gr[v];
+                z_churn = gc[v];
             } else {
-                float unused;
-                philox_normal4(c.seed, c.row_offset + k.row, trial_col(c.trial_offset + k.tl, k.col), (uint32_t)it, z_prev, z_re, z_churn, unused);
+                const uint64_t grow = c.row_offset + k.row;
+                const int gt = c.trial_offset + k.tl;
+                z_prev = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 0);
+                if (add_renoise) z_re = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 1);
+                z_churn = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 2);
             }
             const float xh = xhv.v[v], d = dv.v[v], mk = mkv.v[v];
             const float xe = xh + h * d;
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(256) void k_churn(const float* __restrict__ x_cur, 
         const int col = (int)(e - m * D);
         float z;
         if (eps) z = eps[e];
-        else { float a, b, cc; philox_normal4(seed, row_offset + m, trial_col(0, col), block, a, b, z, cc); }
+        else z = noise_cell(seed, row_offset + m, 0, col, block, 2);
         const float xh = x_cur[e] + churn * z;
         x_hat[e] = xh;
         const float v = c_in * xh;
@@ -327,9 +350,7 @@ __global__ __launch_bounds__(256) void k_noise_field(float* out, int64_t n_rows,
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = e / D;
         const int col = (int)(e - row * D);
-        float z[4];
-        philox_normal4(seed, row_offset + row, trial_col(trial, col), block, z[0], z[1], z[2], z[3]);
-        out[e] = comp == 0 ? z[0] : comp == 1 ? z[1] : comp == 2 ? z[2] : z[3];
+        out[e] = noise_cell(seed, row_offset + row, trial, col, block, comp);
     }
 }
 

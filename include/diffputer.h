@@ -91,7 +91,8 @@ size_t dp_workspace_bytes(const dp_plan* plan, int64_t n_chains);
  *   out        [n_rows, d_in]  sum over the trials of rec*mask + x_obs*(1-mask)
  *   seed, row_offset, trial_offset
  *              counter-based Philox4x32-10 noise keyed by (seed; global row = row_offset + r, global trial =
- *              trial_offset + t, column, draw block): results do not depend on how rows/trials are sharded.
+ *              trial_offset + t, column group, draw block; one block serves the 4 columns of a group): results do not
+ *              depend on how rows/trials are sharded, nor on the alignment of the tables.
  *   noise      NULL, or [num_trials, n_draws, n_rows, d_in] float32: the reference's Gaussian draws in
  *              program order (n_draws = 1 + 4*R*(S-1) + 3, without the + 3 under DP_NO_FINAL_LEVEL; draw 0 =
  *              torch.randn :25, then per inner iteration n_curr :44 (unused), n_prev :45, churn eps :96, n :52).
@@ -118,7 +119,7 @@ int dp_denoise(dp_plan* plan, const float* x, float sigma, float* D_out, float* 
  * One stochastic EDM step.  Replaces: sample_step(net, num_steps, i, t_cur, t_next, x_next)
  * (diffusion_utils.py:90-109): churn to t_hat = 1.02 t_cur (gamma = min(S_churn/S, sqrt2-1)), Euler step,
  * Heun correction iff i < num_steps-1.
- *   eps  [n, d_in] the churn draw of :96, or NULL to use Philox (seed, row_offset, draw block `block`)
+ *   eps  [n, d_in] the churn draw of :96, or NULL to use Philox: the field dp_noise_field(.., trial 0, block, comp 2)
  */
 int dp_sample_step(dp_plan* plan, int i, float t_cur, float t_next, const float* x_cur, const float* eps,
                    float* x_next, int64_t n, uint64_t seed, uint64_t row_offset, uint32_t block,
@@ -193,9 +194,12 @@ int dp_masked_errors(const float* pred, const float* truth, const uint8_t* mask,
                      int num_num, double* sums, void* stream);
 
 /*
- * Fill out[n_rows, d_in] with the Philox Gaussian field of draw block `block`, component `comp` (0..3), for
- * global rows row_offset.. and global trial `trial` (the noise dp_impute uses when noise == NULL).
- * No counterpart in the reference (it uses torch's global RNG, unseeded).
+ * Fill out[n_rows, d_in] with one of the Gaussian fields dp_impute draws when noise == NULL, for global rows
+ * row_offset.. and global trial `trial`: block = inner-iteration index (or 0xFFFFFFFF = before the first iteration),
+ * comp = kind: 0 = n_prev of that iteration (diffusion_utils.py:45; for 0xFFFFFFFF the initial x_T draw :25),
+ * 1 = the re-noise n (:52), 2 = the churn eps (:96) of the NEXT iteration.  Laid out in the reference's draw order these
+ * fields replay a Philox run exactly (tests/test_gpu_parity.py).  No counterpart in the reference (it uses torch's
+ * global RNG, unseeded).
  */
 int dp_noise_field(float* out, int64_t n_rows, int d_in, uint64_t seed, uint64_t row_offset, int trial,
                    uint32_t block, int comp, void* stream);

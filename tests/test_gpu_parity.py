@@ -248,20 +248,75 @@ def _philox_numpy(ctr, key):
 
 
 def test_philox_known_answer_and_box_muller():
+    """dp_noise_field(block = inner iteration, comp = kind) against the addressing dp_philox.h documents: the cell in
+    column c takes component c & 3 of the block (4 * iteration + kind) of its column group c >> 2."""
     from diffputer_amd.sampler import noise_field
     # Random123 known-answer vector for philox4x32-10 (counter = key = 0)
     assert _philox_numpy([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
-    seed, row_offset, trial, block, d = 0x1234567887654321, (1 << 33) + 5, 3, 17, 7
-    got = [noise_field(4, d, seed, row_offset, trial, block, comp, DEV).cpu().numpy() for comp in range(4)]
-    for r in range(4):
-        for c in range(d):
-            grow = row_offset + r
-            x = _philox_numpy([grow & 0xFFFFFFFF, grow >> 32, (trial << 16) | c, block], [seed & 0xFFFFFFFF, seed >> 32])
-            u = [((v >> 8) + 0.5) / 16777216.0 for v in x]
-            ra, rb = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
-            want = [ra * np.cos(2 * np.pi * u[1]), ra * np.sin(2 * np.pi * u[1]), rb * np.cos(2 * np.pi * u[3]), rb * np.sin(2 * np.pi * u[3])]
-            for comp in range(4):
-                assert abs(got[comp][r, c] - want[comp]) <= 2e-5 * max(1.0, abs(want[comp])), (r, c, comp)
+    seed, row_offset, trial, d = 0x1234567887654321, (1 << 33) + 5, 3, 7
+    for it, blk_of in ((17, lambda kind: 4 * 17 + kind), (0xFFFFFFFF, lambda kind: 0xFFFFFFFC + kind)):
+        got = [noise_field(4, d, seed, row_offset, trial, it, kind, DEV).cpu().numpy() for kind in range(3)]
+        for r in range(4):
+            for c in range(d):
+                grow = row_offset + r
+                for kind in range(3):
+                    x = _philox_numpy([grow & 0xFFFFFFFF, grow >> 32, (trial << 16) | (c >> 2), blk_of(kind)],
+                                      [seed & 0xFFFFFFFF, seed >> 32])
+                    u = [((v >> 8) + 0.5) / 16777216.0 for v in x]
+                    ra, rb = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
+                    want = [ra * np.cos(2 * np.pi * u[1]), ra * np.sin(2 * np.pi * u[1]), rb * np.cos(2 * np.pi * u[3]),
+                            rb * np.sin(2 * np.pi * u[3])][c & 3]
+                    assert abs(got[kind][r, c] - want) <= 2e-5 * max(1.0, abs(want)), (it, r, c, kind)
+
+
+@pytest.mark.parametrize("d", [9, 12])
+def test_philox_mode_equals_replay_of_its_own_field(d):
+    """Production mode (in-kernel Philox) must be replay mode fed the same numbers: dp_noise_field laid out in the
+    reference's draw order (kind 0 = n_prev :45, 1 = n :52, 2 = the churn eps :96 of the NEXT iteration).  d = 9 runs the
+    one-cell-per-thread kernels (a cell evaluates its group's block and keeps one component), d = 12 the four-cell ones
+    (a thread evaluates its group's block once): every x_t bit for bit."""
+    from diffputer_amd.sampler import n_draws, noise_field
+    hid, S, R, n, seed, ro, T = 64, 5, 3, 6, 11, 100, 2
+    sd = synth.make_weights(d, hid, 3, 1.5)
+    X, mask = synth.make_table(n, d, seed=4)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    p = _plan(sd, S, R, "f32")
+    nd = n_draws(S, R)
+    nz = torch.zeros((T, nd, n, d), device=DEV)
+    INIT = 0xFFFFFFFF
+    for t in range(T):
+        f = lambda block, comp: noise_field(n, d, seed, ro, t, block, comp, DEV)
+        nz[t, 0] = f(INIT, 0)
+        for it in range(R * (S - 1) + 1):
+            base = 1 + 4 * it
+            nz[t, base + 1] = f(it, 0)
+            nz[t, base + 2] = f(INIT, 2) if it == 0 else f(it - 1, 2)
+            if base + 3 < nd:
+                nz[t, base + 3] = f(it, 1)
+    a, tra = p.impute_sum(x_obs, mask, T, seed=seed, row_offset=ro, trace=True)
+    b, trb = p.impute_sum(x_obs, mask, T, noise=nz, trace=True)
+    assert torch.equal(tra, trb) and torch.equal(a, b)
+    p.close()
+
+
+def test_alignment_does_not_change_results():
+    """The four-cells-per-thread kernels need 16-byte aligned tables; a table that is not (a view one float into a buffer)
+    takes the one-cell kernels and must give the same bits -- the noise of a cell does not depend on who evaluates it."""
+    d, hid, S, R, n, T = 16, 64, 4, 3, 50, 3
+    sd = synth.make_weights(d, hid, 71, 1.5)
+    X, mask = synth.make_table(n, d, seed=72)
+    x_obs = torch.from_numpy((X * (1.0 - mask)).astype(np.float32)).to(DEV)
+    m8 = torch.from_numpy(mask).to(DEV).to(torch.uint8)
+    for dtype in ("f32", "bf16"):
+        p = _plan(sd, S, R, dtype)
+        aligned, _ = p.impute_sum(x_obs, m8, T, seed=9)
+        buf = torch.zeros(n * d + 1, device=DEV)
+        shifted = buf[1:].view(n, d)
+        shifted.copy_(x_obs)
+        assert shifted.data_ptr() % 16 == 4 and shifted.is_contiguous()
+        other, _ = p.impute_sum(shifted, m8, T, seed=9)
+        assert torch.equal(aligned, other), dtype
+        p.close()
 
 
 def test_philox_field_statistics():
