@@ -240,11 +240,14 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     bool first = true;
 
 #ifdef DP_PP_STAMP
-    unsigned long long stamp[5];
+    unsigned long long stamp[6];
     int round = 0;
 #endif
     for (;;) {
         PP_STAMP(0);
+#ifdef DP_PP_STAMP
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[5]) :: "memory");   // wall clock (100 MHz) at tile start
+#endif
         f32x4 acc[2][4][2][2];                                   // [A half][m-tile][B half][n-tile]
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -404,6 +407,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         if (g_pp_stamp_buf && round < 16 && (tid & 255) == 0) {                     // wave 0 and wave 4 (one per wave row)
             unsigned long long* d = g_pp_stamp_buf + (((size_t)blockIdx.x * 16 + round) * 2 + (tid >> 8)) * 8;
             for (int k = 0; k < 5; ++k) d[k] = stamp[k];
+#ifndef DP_PP_PHASES
+            d[5] = stamp[5];
+#endif
 #ifdef DP_PP_PHASES
             for (int k = 0; k < 3; ++k) d[5 + k] = ph_acc[k];     // c3 = K loop - (c0 + c1 + c2)
 #endif

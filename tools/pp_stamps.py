@@ -63,6 +63,12 @@ if os.environ.get("DP_COLD"):                                       # one launch
         run()
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
+e0.record()
+for _ in range(50):
+    run()
+e1.record()
+torch.cuda.synchronize()
+ms_b2b = e0.elapsed_time(e1) / 50                                   # back to back, as in the sampler's stream
 s = buf.cpu().numpy().reshape(grid, 16, 2, 8).astype(np.float64)
 rounds = int((s[0, :, 0, 0] > 0).sum())
 print(f"M={a.m} N={a.n} K={a.k}: launch {ms*1e3:.1f} us = {2.0*a.m*a.n*a.k/ms/1e9:.1f} TFLOP/s, rounds {rounds}")
@@ -83,6 +89,13 @@ if s[:, :, :, 5].max() > 0:                                             # -DDP_P
         c = [np.median(d[:, 5 + k]) / nk for k in range(3)]
         c.append(np.median(loop - d[:, 5] - d[:, 6] - d[:, 7]) / nk)
         print(f"wave row {row}: cycles per phase c0..c3 = " + " ".join(f"{x:.0f}" for x in c) + f"  (sum {sum(c):.0f}; MFMA-bound would be 512 each)")
+if s[:, 0, 0, 5].max() > 1e6 and s[:, :, :, 6].max() == 0:             # plain stamp build: wall-clock (100 MHz) start of every tile
+    t_first = s[:, 0, 0, 5]
+    t_last_end = s[:, rounds - 1, 0, 4]
+    t0 = t_first.min()
+    print(f"wall clock: workgroups start over {(t_first.max() - t0) / 100:.1f} us (median {(np.median(t_first) - t0) / 100:.1f}), "
+          f"end between {(t_last_end.min() - t0) / 100:.1f} and {(t_last_end.max() - t0) / 100:.1f} us (median {(np.median(t_last_end) - t0) / 100:.1f}); "
+          f"launch by events {ms * 1e3:.1f} us alone, {ms_b2b * 1e3:.1f} us back to back")
 tot_cycles = (s[:, rounds - 1, 0, 3] - s[:, 0, 0, 0])
 tot_real = (s[:, rounds - 1, 0, 4] - s[:, 0, 0, 4])
 print(f"kernel span per WG: med {np.median(tot_cycles):.0f} cycles")
