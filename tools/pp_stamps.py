@@ -96,6 +96,17 @@ if s[:, 0, 0, 5].max() > 1e6 and s[:, :, :, 6].max() == 0:             # plain s
     print(f"wall clock: workgroups start over {(t_first.max() - t0) / 100:.1f} us (median {(np.median(t_first) - t0) / 100:.1f}), "
           f"end between {(t_last_end.min() - t0) / 100:.1f} and {(t_last_end.max() - t0) / 100:.1f} us (median {(np.median(t_last_end) - t0) / 100:.1f}); "
           f"launch by events {ms * 1e3:.1f} us alone, {ms_b2b * 1e3:.1f} us back to back")
+if rounds > 1 and s[:, 0, 0, 5].max() > 1e6 and s[:, :, :, 6].max() == 0:
+    # is a workgroup's speed a property of where it runs?  wall-clock duration of the whole kernel per workgroup, by XCD
+    # (workgroup id % 8) and spread within an XCD; and the correlation of a workgroup's duration between two launches
+    dur = (s[:, rounds - 1, 0, 4] - s[:, 0, 0, 5]) / 100.0
+    by = [dur[x::8] for x in range(8)]
+    print("per-XCD median duration [us]: " + " ".join(f"{np.median(b):.1f}" for b in by) +
+          f" | within-XCD spread (p95-p5) {np.median([np.percentile(b, 95) - np.percentile(b, 5) for b in by]):.1f}")
+    run(); torch.cuda.synchronize()
+    s2 = buf.cpu().numpy().reshape(grid, 16, 2, 8).astype(np.float64)
+    dur2 = (s2[:, rounds - 1, 0, 4] - s2[:, 0, 0, 5]) / 100.0
+    print(f"correlation of per-workgroup duration between two launches: {np.corrcoef(dur, dur2)[0, 1]:.2f}")
 tot_cycles = (s[:, rounds - 1, 0, 3] - s[:, 0, 0, 0])
 tot_real = (s[:, rounds - 1, 0, 4] - s[:, 0, 0, 4])
 print(f"kernel span per WG: med {np.median(tot_cycles):.0f} cycles")
