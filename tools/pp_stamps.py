@@ -81,7 +81,7 @@ for r in range(rounds):
     start = d[:, 0, 0] - t0_all
     print(f"round {r}: start {np.median(start):9.0f} (min {start.min():9.0f} max {start.max():9.0f}) | prologue wait med {np.median(pro):7.0f} max {pro.max():7.0f} | "
           f"K loop med {np.median(loop):7.0f} min {loop.min():7.0f} max {loop.max():7.0f} | epilogue med {np.median(epi):6.0f} max {epi.max():6.0f}  [cycles]")
-if s[:, :, :, 5].max() > 0:                                             # -DDP_PP_PHASES build: cycles per phase type
+if s[:, :, :, 6].max() > 0:                                             # -DDP_PP_PHASES build: cycles per phase type
     nk = a.k // 64
     for row in range(2):
         d = s[:, 1, row]
