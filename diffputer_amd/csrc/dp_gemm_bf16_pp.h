@@ -49,7 +49,7 @@ constexpr int PP_LDS_TOTAL = PP_LDS_BYTES + 8 * PP_STAGE_WAVE;  // 160 KiB: the 
 // Diagnostic build only (-DDP_PP_STAMP, tools/pp_stamps.py): s_memtime / s_memrealtime stamps per workgroup and round,
 // written to a buffer of their own; no stamp executes in the shipped library.
 #ifdef DP_PP_STAMP
-__device__ unsigned long long* g_pp_stamp_buf = nullptr;        // [gridDim][16 rounds][8]
+__device__ unsigned long long* g_pp_stamp_buf = nullptr;        // [gridDim][16 rounds][2 wave rows][8]
 #define PP_STAMP(k)                                                                                             \
     do {                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -315,6 +315,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
             n0 = tile_n0(tile);
             if (PREFETCH) prologue(m0, n0);
         }
+        // The counted waits of the next tile's K-tile 0 (PP_WAIT_T0, the vmcnt(8 + NST) above) assume the in-order vmcnt
+        // queue holds [prologue DMA][NST epilogue stores]: pin that order -- nothing of the epilogue may be scheduled above
+        // this point, nothing of the prologue below it.
+        __builtin_amdgcn_sched_barrier(0);
 
         if (EPI == EPI_MID) {
             const int64_t row0 = om + (elane & 15);
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
                     *(uint4*)(o + (size_t)24 * ldo) = r3;
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);                       // ... and no epilogue store below this point (next tile's DMA)
 #ifdef DP_PP_STAMP
         PP_STAMP(3);
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[4]) :: "memory");

@@ -162,10 +162,12 @@ __global__ __launch_bounds__(256) void k_step_mid(StepCommon c, float c_skip, fl
 
 // After the second evaluation: Heun, observed-value blend, re-noise, next churn.
 //   it = global inner-iteration index; renoise > 0 iff j < R-1; churn_next/c_in_next belong to iteration it+1.
+//   has_next = 0 on the last iteration of a run without the final level (DP_NO_FINAL_LEVEL): no iteration it+1 exists, so
+//   its churn draw is not taken (a replay buffer holds no such draw) and x_hat / u are left as they are.
 template <int V>
 __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_skip, float c_out, float t_next, float h,
                                                   float renoise, int add_renoise, float churn_next, float c_in_next,
-                                                  float* __restrict__ xt_out) {
+                                                  float* __restrict__ xt_out, int has_next) {
     const int64_t nv = c.n_cells / V;
     const float inv_t_next = 1.0f / t_next;
     for (int64_t ev = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ev < nv; ev += (int64_t)gridDim.x * blockDim.x) {
@@ -181,26 +183,26 @@ __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_
             const int gt = c.trial_offset + k.tl;
             noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 0, gp);
             if (add_renoise) noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 1, gr);
-            noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 2, gc);
+            if (has_next) noise_group4(c.seed, grow, gt, k.col, (uint32_t)it, 2, gc);
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            float z_prev, z_re = 0.f, z_churn;
+            float z_prev, z_re = 0.f, z_churn = 0.f;
             if (c.noise) {
                 const int64_t base = 1 + 4 * (int64_t)it;
                 z_prev = draw(c, k, base + 1);
                 z_re = add_renoise ? draw(c, k, base + 3) : 0.f;
-                z_churn = draw(c, k, base + 4 + 2);      // churn draw of iteration it+1
+                if (has_next) z_churn = draw(c, k, base + 4 + 2);      // churn draw of iteration it+1
             } else if (V == 4) {
                 z_prev = gp[v];
                 if (add_renoise) z_re = gr[v];
-                z_churn = gc[v];
+                if (has_next) z_churn = gc[v];
             } else {
                 const uint64_t grow = c.row_offset + k.row;
                 const int gt = c.trial_offset + k.tl;
                 z_prev = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 0);
                 if (add_renoise) z_re = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 1);
-                z_churn = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 2);
+                if (has_next) z_churn = noise_cell(c.seed, grow, gt, k.col, (uint32_t)it, 2);
             }
             const float xh = xhv.v[v], d = dv.v[v], mk = mkv.v[v];
             const float xe = xh + h * d;
@@ -217,8 +219,10 @@ __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_
         }
         if (c.trace) stf<V>(c.trace + (int64_t)it * c.n_cells + e, xt);
         if (xt_out) stf<V>(xt_out + e, xt);                       // DP_NO_FINAL_LEVEL: x_t itself is the result
-        stf<V>(c.x_hat + e, xh2);
-        store_u<V>(c, k.m, k.col - V, uu);
+        if (has_next) {
+            stf<V>(c.x_hat + e, xh2);
+            store_u<V>(c, k.m, k.col - V, uu);
+        }
     }
 }
 

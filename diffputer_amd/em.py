@@ -54,6 +54,16 @@ def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, b
     return model, best
 
 
+def broadcast_model(model, loss: float, src: int = 0):
+    """Every rank leaves with rank `src`'s parameters (in place, tensor by tensor in state-dict order) and its loss."""
+    import torch.distributed as dist
+    for t in model.state_dict().values():
+        dist.broadcast(t, src=src)
+    box = torch.tensor([loss], dtype=torch.float64, device=next(model.parameters()).device)
+    dist.broadcast(box, src=src)
+    return model, float(box.item())
+
+
 @dataclass
 class EMResult:
     mae_in: list = field(default_factory=list)
@@ -68,8 +78,16 @@ def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, m
            num_steps: int = 50, device="cuda:0", ckpt_dir: str | None = None, max_epochs: int = 10001, dtype: str | None = None,
            seed: int = 0, num_num: int | None = None, oos_drop_rows=None, log=print) -> EMResult:
     """X, X_test: normalised tables ((x - mean)/std/2, main.py:58,61) holding the TRUE values (used for scoring only, like the
-    reference); masks True = missing.  Under torch.distributed the E-step shards rows over ranks (estep.e_step).
-    `oos_drop_rows`: rows of the test table left out of its score (news: [6265], dataset.py:194-197)."""
+    reference); masks True = missing.
+    `oos_drop_rows`: rows of the test table left out of its score (news: [6265], dataset.py:194-197).
+
+    Under torch.distributed (every rank calls this with the same tables): the M-step runs on rank 0 only -- the reference
+    has ONE trainer and GPU training is not bit-reproducible across ranks -- and its best weights are broadcast, so every
+    rank's row shard of the E-step is sampled from the same model; rank 0 alone writes model.pt / iter_k.npy (one writer,
+    as in the reference), followed by a barrier so that no rank runs ahead of the files."""
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if distributed else 0
     dev = torch.device(device)
     X = torch.as_tensor(X).to(dev, torch.float32).contiguous()
     m_tr = torch.as_tensor(mask_train).to(dev).contiguous()
@@ -78,15 +96,22 @@ def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, m
     train_data = (1.0 - m_tr.float()) * X                                     # iteration 0: zero-filled (main.py:84-86)
     for it in range(max_iter):
         log(f"EM iteration {it}: M-step on {tuple(train_data.shape)}")
-        model, loss = m_step(train_data, hid_dim, max_epochs=max_epochs, generator=gen, log=log)
+        if rank == 0:
+            model, loss = m_step(train_data, hid_dim, max_epochs=max_epochs, generator=gen, log=log)
+        else:
+            model, loss = Model(denoise_fn=MLPDiffusion(X.shape[1], hid_dim), hid_dim=X.shape[1]).to(dev).eval(), 0.0
+        if distributed:
+            model, loss = broadcast_model(model, loss, src=0)
         res.train_loss.append(loss)
-        if ckpt_dir:
+        if ckpt_dir and rank == 0:
             formats.save_checkpoint(os.path.join(ckpt_dir, str(it), "model.pt"), model)
         net = model.denoise_fn_D
         rec = estep.e_step(net, X, m_tr, num_trials, num_steps, dev, seed=seed + 1000 * it, dtype=dtype)       # main.py:156-188
         rec2 = rec * 2                                                        # main.py:190
-        if ckpt_dir:
+        if ckpt_dir and rank == 0:
             formats.save_iteration(os.path.join(ckpt_dir, f"iter_{it + 1}.npy"), rec2)
+        if distributed:
+            dist.barrier()
         mae, rmse = prep.masked_errors(rec2, X * 2, m_tr, num_num)             # main.py:201
         res.mae_in.append(mae); res.rmse_in.append(rmse)
         log(f"  in-sample      MAE {mae:.4f} RMSE {rmse:.4f}")

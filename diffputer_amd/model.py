@@ -8,8 +8,6 @@ match the reference so `model.pt` checkpoints interchange (main.py:142,173).
 """
 from __future__ import annotations
 
-import math
-
 import torch
 from torch import nn
 
@@ -130,4 +128,4 @@ def nfe_per_chain(num_steps: int, n_resample: int) -> int:
 
 
 __all__ = ["PositionalEmbedding", "MLPDiffusion", "Precond", "EDMLoss", "Model",
-           "num_parameters", "flops_per_row_eval", "nfe_per_chain", "math"]
+           "num_parameters", "flops_per_row_eval", "nfe_per_chain"]

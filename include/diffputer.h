@@ -16,7 +16,12 @@
  *   - Return value 0 = DP_OK, negative = error; dp_last_error() gives the message (thread-local).
  *   - Tables are row-major float32 [rows, d_in]; masks are uint8 [rows, d_in] with 1 = MISSING
  *     (generate_mask.py:513-514, main.py:85).
- *   - A plan is bound to the device that was current at dp_plan_create and is not thread-safe.
+ *   - A plan is bound to the device that was current at dp_plan_create.
+ *   - Threading: distinct plans may be driven from distinct threads at the same time (per-device launch state is set up
+ *     once under a lock in dp_plan_create and read-only afterwards; dp_last_error is thread-local).  ONE plan must not be
+ *     used from two threads at once (its profiling slots and scratch embedding rows are unsynchronised).  dp_tune values
+ *     are process-wide atomics read at every evaluation: changing one while another thread is inside a sampler call gives
+ *     that call a mix of old and new settings ("fold_proj" changes the rounding sequence, the others do not change bits).
  */
 #ifndef DIFFPUTER_H
 #define DIFFPUTER_H

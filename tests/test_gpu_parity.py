@@ -118,7 +118,9 @@ def test_schedule_and_levels():
         p = _plan(synth.make_weights(9, 64, 1), S, 20, "f32")
         t = p.schedule()
         ref = g[f"t_S{S}"]
-        assert np.all(np.abs(t - ref) <= 2 * np.spacing(ref)), t - ref
+        # bit for bit: S = 5 and 10 by float32 arithmetic op by op, S = 50 (the reference's default, where torch's vectorised
+        # pow is 1 ulp off powf at one level) from the reference's own table (dp_plan_create)
+        assert np.array_equal(t.view(np.uint32), ref.view(np.uint32)), t - ref
         lv = p.levels()
         th = (t[:-1] + np.float32(min(1.0 / S, np.sqrt(2) - 1)) * t[:-1]).astype(np.float32)
         assert np.allclose(lv[0::2], th, rtol=1e-6) and np.allclose(lv[1::2], t[1:-1], rtol=1e-6)
@@ -436,6 +438,29 @@ def test_missdiff_variant_golden():
     assert float(np.abs(g["out"][~mk] - g["x_obs"][~mk]).max()) < 0.02
     b = missdiff.impute_mask(net, x, m, int(g["n"]), int(g["d_in"]), int(g["S"]), DEV, noise=g["noise"], dtype="bf16").cpu().numpy()
     assert float(np.abs(b[mk] - g["out"][mk]).max()) <= 1e-1 * max(1.0, float(np.abs(g["out"]).max()))
+
+
+def test_no_final_level_takes_no_draw_past_the_replay_buffer():
+    """DP_NO_FINAL_LEVEL: the last inner iteration has no successor, so the kernel that ends it must not fetch "the next
+    iteration's churn draw" -- index n_draws + 2 of a buffer that holds n_draws.  The replay buffer here is the head of a
+    larger allocation whose tail is NaN: a draw taken past the end would put NaN into the sampler state x_hat (first
+    buffer of the workspace), which a correct run leaves finite."""
+    d, hid, S, R, n, T = 12, 64, 4, 3, 20, 2
+    p = _plan(synth.make_weights(d, hid, 5, 1.0), S, R, "f32")
+    X, mask = synth.make_table(n, d, seed=6)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    nd = synth.n_draws(S, R) - 3                                      # no final level: 1 + 4 R (S-1)
+    stream = np.stack([synth.reference_noise(40 + t, nd, (n, d)) for t in range(T)])
+    numel = stream.size
+    big = torch.full((numel + 8 * n * d,), float("nan"), device=DEV)
+    big[:numel] = torch.from_numpy(stream).reshape(-1).to(DEV)
+    noise = big[:numel].view(T, nd, n, d)
+    out, _ = p.impute_sum(x_obs, mask, T, noise=noise, final_level=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    x_hat = p._ws[: T * n * d * 4].view(torch.float32)
+    assert bool(torch.isfinite(x_hat).all()), "a draw was read past the end of the replay buffer"
+    p.close()
 
 
 def test_device_prep_and_scoring_golden():

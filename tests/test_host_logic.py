@@ -66,7 +66,9 @@ def test_shard_bounds_cover_rows_exactly():
 
 
 def test_plan_calls_cover_rows_times_trials_once():
-    for n, T, mc in ((18389, 20, 65536), (100, 7, 65536), (200000, 3, 65536), (65536, 2, 65536), (5, 50, 8)):
+    # the last two have more rows than 64 calls of `mc` chains can hold: the planner's one-trial-per-call fallback
+    for n, T, mc in ((18389, 20, 65536), (100, 7, 65536), (200000, 3, 65536), (65536, 2, 65536), (5, 50, 8),
+                     (5_000_000, 2, 65536), (1000, 3, 8)):
         seen = np.zeros((n, T), dtype=np.int32)
         for r0, r1, t0, t1 in estep.plan_calls(n, T, mc):
             assert (r1 - r0) * (t1 - t0) <= mc
@@ -185,6 +187,46 @@ def test_e_step_world_size_2_gloo(shard):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True, (n, d)), (1, True, (n, d))]
+
+
+def _em_worker(rank, world, port, ckpt_dir, q):
+    import torch.distributed as dist
+    from diffputer_amd import em, prep
+    from diffputer_amd.evalmetrics import mae_rmse
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different initialisations: only a broadcast can make the ranks agree
+    sums = []
+
+    def fake_plan_for(net, *a, **k):
+        sums.append(float(sum(p.double().sum() for p in net.parameters())))
+        return _FakePlan()
+
+    estep.plan_for = fake_plan_for
+    prep.masked_errors = lambda pred, truth, m, num_num=None, drop_rows=None: mae_rmse(pred.numpy(), truth.numpy(), m.numpy())
+    X, mask = synth.make_table(64, 4, seed=1)
+    res = em.run_em(X, mask, hid_dim=64, max_iter=2, num_trials=2, num_steps=5, device="cpu", ckpt_dir=ckpt_dir, max_epochs=2,
+                    log=lambda *_: None)
+    q.put((rank, sums, res.train_loss))
+    dist.destroy_process_group()
+
+
+def test_run_em_world_size_2_gloo_one_trainer_one_writer(tmp_path):
+    """em.run_em under torch.distributed: rank 0 trains, its weights and loss are broadcast (every rank samples its row shard
+    from the SAME model), and only rank 0 writes model.pt / iter_k.npy."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_em_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    (_, sums0, loss0), (_, sums1, loss1) = res
+    assert len(sums0) == 2 and sums0 == sums1 and loss0 == loss1, res
+    assert sorted(os.listdir(tmp_path)) == ["0", "1", "iter_1.npy", "iter_2.npy"]
+    assert os.listdir(tmp_path / "0") == ["model.pt"]
 
 
 def test_prep_helpers_match_reference():

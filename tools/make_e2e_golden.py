@@ -43,6 +43,7 @@ ap.add_argument("--epochs", type=int, default=400)
 ap.add_argument("--replay-rows", type=int, default=256)
 ap.add_argument("--trials", type=int, default=5)
 ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--trace-every", type=int, default=0, help="replay run: also store x_t after every k-th inner iteration (0 = off)")
 a = ap.parse_args()
 sys.argv = sys.argv[:1]                       # the modules below must not see our flags
 torch.set_num_threads(a.threads)
@@ -119,14 +120,27 @@ net = model.denoise_fn_D
 S, R = 50, 20
 
 
-def e_step(x_full, m_full, trials, replay=None):
+def e_step(x_full, m_full, trials, replay=None, starts=None):
+    """main.py:212-246.  `starts` (a list) receives the x_t handed to every sample_step call (the state BEFORE each inner
+    iteration), captured by wrapping the reference's sample_step for the duration of the call."""
     recs = []
     for trial in range(trials):
         impute_X = (1.0 - m_full.float()) * x_full
         with torch.no_grad():
             if replay is not None:
-                with NoiseReplay(replay[trial]) as nr:
-                    rec = ref_du.impute_mask(net, impute_X, m_full, impute_X.shape[0], impute_X.shape[1], S, "cpu")
+                saved = ref_du.sample_step
+
+                def spy(net_, num_steps, i, t_cur, t_next, x_next):
+                    if starts is not None:
+                        starts.append(x_next.numpy().copy())
+                    return saved(net_, num_steps, i, t_cur, t_next, x_next)
+
+                ref_du.sample_step = spy
+                try:
+                    with NoiseReplay(replay[trial]) as nr:
+                        rec = ref_du.impute_mask(net, impute_X, m_full, impute_X.shape[0], impute_X.shape[1], S, "cpu")
+                finally:
+                    ref_du.sample_step = saved
                 assert nr.k == replay.shape[1]
             else:
                 rec = ref_du.impute_mask(net, impute_X, m_full, impute_X.shape[0], impute_X.shape[1], S, "cpu")
@@ -144,7 +158,16 @@ nr_rows = a.replay_rows
 nseed = 777
 stream = synth.reference_noise(nseed, synth.n_draws(S, R), (nr_rows, in_dim))
 t0 = time.time()
-rep = e_step(X_test[:nr_rows], mask_test[:nr_rows], 1, replay=stream[None])
+starts = [] if a.trace_every else None
+rep = e_step(X_test[:nr_rows], mask_test[:nr_rows], 1, replay=stream[None], starts=starts)
+trace_kw = {}
+if a.trace_every:
+    # x_t after inner iteration k = the x_t handed to iteration k+1; the last one is impute_mask's return value, which for
+    # finite values equals the blended `rep` (main.py:182-183 is then a no-op)
+    full = np.stack(starts[1:] + [rep.numpy()])
+    idx = np.arange(full.shape[0])
+    keep = (idx % a.trace_every == a.trace_every - 1) | (idx == full.shape[0] - 1)
+    trace_kw = dict(trace=full[keep], trace_idx=idx[keep])
 print(f"replay E-step: {time.time() - t0:.0f}s  MAE/RMSE {metrics(rep, X_test[:nr_rows], mask_test[:nr_rows])}")
 free, free_out = [], []
 for seed in (0, 1):
@@ -163,5 +186,5 @@ np.savez_compressed(
     path, **{"sd__" + k: v for k, v in out.items()}, hid=a.hid, d_in=in_dim, S=S, R=R, epochs=a.epochs, train_loss=best,
     X_test=X_test.numpy(), mask_test=mask_test.numpy(), replay_rows=nr_rows, nseed=nseed, noise_checksum=checksum(stream),
     replay_out=rep.numpy(), replay_mae_rmse=np.asarray(metrics(rep, X_test[:nr_rows], mask_test[:nr_rows])),
-    free_trials=a.trials, free_mae_rmse=np.asarray(free), free_out=np.asarray(free_out), zero_fill_mae_rmse=np.asarray(zero))
+    free_trials=a.trials, free_mae_rmse=np.asarray(free), free_out=np.asarray(free_out), zero_fill_mae_rmse=np.asarray(zero), **trace_kw)
 print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")

@@ -30,7 +30,7 @@ A = torch.randn(a.m, a.k, device=dev, generator=g).bfloat16()
 W = (torch.randn(a.n, a.k, device=dev, generator=g) / a.k ** 0.5).bfloat16()
 b = torch.randn(a.n, device=dev, generator=g)
 out = torch.empty(a.m, a.n, device=dev, dtype=torch.bfloat16)
-grid = 256
+grid = torch.cuda.get_device_properties(0).multi_processor_count   # the kernel indexes the buffer by blockIdx.x < min(tiles, CUs)
 buf = torch.zeros(grid * 16 * 2 * 8, dtype=torch.int64, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
