@@ -16,6 +16,7 @@ DP_DTYPE_F32 = 0
 DP_DTYPE_BF16 = 1
 DP_ACCUMULATE = 1
 DP_NO_FINAL_LEVEL = 2
+DP_STATIC_SCRATCH_BYTES = 32 << 20
 
 # every symbol include/diffputer.h declares: (restype, argtypes)
 _vp, _i, _i64, _u64, _u32, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_float, C.c_size_t
@@ -27,6 +28,7 @@ SIGNATURES = {
     "dp_plan_destroy": (None, [_vp]),
     "dp_workspace_bytes": (_sz, [_vp, _i64]),
     "dp_impute": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _u64, _u64, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "dp_impute_static": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _u64, _u64, _i, _vp, _vp, _i, _vp]),
     "dp_denoise": (_i, [_vp, _vp, _f, _vp, _vp, _i64, _vp, _sz, _vp]),
     "dp_sample_step": (_i, [_vp, _i, _f, _f, _vp, _vp, _vp, _i64, _u64, _u64, _u32, _vp, _sz, _vp]),
     "dp_plan_schedule": (_i, [_vp, C.POINTER(_f)]),

@@ -68,6 +68,7 @@ struct dp_plan {
     int prof_used = 0;                   // samples recorded
     std::vector<hipEvent_t> prof_ev;     // DP_PROF_SAMPLES * 7 events: before GEMM-1, after GEMM-1..5, after the step kernel
     std::vector<int> prof_tag;           // which step kernel followed: 0 mid, 1 end, 2 final
+    void* static_ws = nullptr;           // this device's copy of the file-scope scratch array (dp_impute_static), resolved at create
     size_t esize() const { return dtype == DP_DTYPE_BF16 ? 2 : 4; }
 };
 #define DP_PROF_SAMPLES 256
@@ -89,11 +90,16 @@ static std::atomic<int> g_m_chunk{32768};  // "m_chunk": rows per launch of the 
 static std::atomic<int> g_fuse_mid{1};     // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 static inline int tune(const std::atomic<int>& v) { return v.load(std::memory_order_relaxed); }
 
+// dp_impute_static's scratch: device memory beyond the caller's tables, held by every GPU the library runs on until the
+// process ends.  On the host this name is only a handle for hipGetSymbolAddress; the address kernels and memsets use is
+// DeviceState::scratch (one per device: each GPU has its own copy of the array at its own address).
+static __device__ __align__(256) unsigned char scratch[DP_STATIC_SCRATCH_BYTES];
+
 // Per-device launch state (a process normally drives one GPU, but nothing here may assume it): CU count for the
-// persistent kernel's grid, the dynamic-LDS attribute of every GEMM variant.
+// persistent kernel's grid, the dynamic-LDS attribute of every GEMM variant, the address of this device's scratch array.
 // Filled once per device under a mutex, by dp_plan_create (or by the first dp_linear on a device that has no plan), with
 // that device current; afterwards read-only, so launches take no lock and make no set-up call.
-struct DeviceState { std::atomic<int> ready{0}; int num_cus = 0; };
+struct DeviceState { std::atomic<int> ready{0}; int num_cus = 0; void* scratch = nullptr; };
 static DeviceState g_dev[64];
 static std::mutex g_dev_mutex;
 static int current_device() {
@@ -175,6 +181,10 @@ static int ensure_device_ready(int dev) {
     DP_ATTR4(256, 64, 4, 1);
 #undef DP_ATTR4
 #undef DP_ATTR
+    // this device's copy of the scratch array: from here on host code uses d.scratch, never the array's name
+    void* sp = nullptr;
+    DP_HIP(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+    d.scratch = sp;
     d.ready.store(1, std::memory_order_release);
     return DP_OK;
 }
@@ -360,6 +370,13 @@ static void free_plan_buffers(dp_plan* p) {
     for (auto q : f) { if (*q) (void)hipFree(*q); *q = nullptr; }
 }
 
+// chains that fit the static scratch array for this plan: carve() grows in steps of 256 chains (the GEMM row padding)
+static int64_t static_max_chains(const dp_plan* p) {
+    int64_t n = 0;
+    while (carve(p, n + 256, nullptr).bytes <= DP_STATIC_SCRATCH_BYTES) n += 256;
+    return n;
+}
+
 }  // namespace dp
 
 // ================================================================================================================
@@ -384,9 +401,11 @@ int dp_plan_create(dp_plan** out, int d_in, int hid, int num_steps, int n_resamp
     p->n_levels = 2 * num_steps - 1;
     hipError_t e = hipGetDevice(&p->device);
     if (e != hipSuccess) { delete p; return fail(DP_EHIP, "hipGetDevice failed: %s", hipGetErrorString(e)); }
-    // one-time set-up of this device (CU count, dynamic-LDS attributes): after this no sampler call makes a set-up call
+    // one-time set-up of this device (CU count, dynamic-LDS attributes, address of its scratch array): after this no
+    // sampler call makes a set-up or allocating HIP call
     const DeviceState* ds = device_state();
     if (!ds) { delete p; return DP_EHIP; }
+    p->static_ws = ds->scratch;
 
     // sigma schedule (diffusion_utils.py:24,27-32), float32 op by op; sigma_min = max(0.002, 0), sigma_max = min(80, inf)
     const int S = num_steps;
@@ -580,6 +599,24 @@ int dp_impute(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, i
     if (rc) return rc;
     return impute_impl(p, x_obs, mask, out, n_rows, num_trials, seed, row_offset, trial_offset, noise, trace, flags, workspace,
                        workspace_bytes, stream);
+}
+
+// dp_impute on the library's own scratch array instead of a caller workspace: no hipMalloc / hipFree / allocating call
+// on this path (device set-up happened in dp_plan_create; the kernels take the array's per-device address as an ordinary
+// pointer argument, exactly as they take a caller's workspace).
+int dp_impute_static(dp_plan* p, const float* x_obs, const uint8_t* mask, float* out, int64_t n_rows, int num_trials, uint64_t seed,
+                     uint64_t row_offset, int trial_offset, const float* noise, float* trace, int flags, void* stream) {
+    int rc = check_plan(p, true);
+    if (rc) return rc;
+    if (n_rows <= 0 || num_trials <= 0) return fail(DP_EINVAL, "n_rows=%lld and num_trials=%d must be positive", (long long)n_rows, num_trials);
+    if (!p->static_ws) return fail(DP_ESTATE, "the plan has no static scratch address");
+    const int64_t M = n_rows * num_trials;
+    const size_t need = carve(p, M, nullptr).bytes;
+    if (need > DP_STATIC_SCRATCH_BYTES)
+        return fail(DP_EWORKSPACE, "dp_impute_static: %lld chains need %zu bytes of scratch, the static array holds %zu (%lld chains for this plan); "
+                    "use dp_impute with a caller workspace", (long long)M, need, (size_t)DP_STATIC_SCRATCH_BYTES, (long long)static_max_chains(p));
+    return impute_impl(p, x_obs, mask, out, n_rows, num_trials, seed, row_offset, trial_offset, noise, trace, flags, p->static_ws,
+                       DP_STATIC_SCRATCH_BYTES, stream);
 }
 
 int dp_plan_profile(dp_plan* p, int stride) {

@@ -146,9 +146,12 @@ class SamplerPlan:
         return x, m
 
     def impute_sum(self, x_obs, mask, num_trials: int = 1, *, seed: int = 0, row_offset: int = 0, trial_offset: int = 0,
-                   noise=None, trace: bool = False, out=None, accumulate: bool = False, final_level: bool = True):
+                   noise=None, trace: bool = False, out=None, accumulate: bool = False, final_level: bool = True,
+                   static_scratch: bool = False):
         """One `dp_impute` call: all `num_trials` trials of all rows as one batch of chains.
-        Returns (sum over trials [n, D], trace or None).  final_level=False: DP_NO_FINAL_LEVEL (the MissDiff variant)."""
+        Returns (sum over trials [n, D], trace or None).  final_level=False: DP_NO_FINAL_LEVEL (the MissDiff variant).
+        static_scratch=True: `dp_impute_static` -- the library's own scratch array instead of a torch workspace (small
+        calls only; the C call then allocates nothing, pass `out` to keep this wrapper from allocating too)."""
         x, m = self._prep(x_obs, mask)
         n = x.shape[0]
         if n == 0:
@@ -171,12 +174,19 @@ class SamplerPlan:
         if trace:
             tr = torch.empty((n_iter(self.num_steps, self.n_resample, final_level), num_trials, n, self.d_in), dtype=torch.float32,
                              device=self.device)
+        flags = (_lib.DP_ACCUMULATE if accumulate else 0) | (0 if final_level else _lib.DP_NO_FINAL_LEVEL)
+        if static_scratch:
+            with torch.cuda.device(self.device):
+                rc = self.lib.dp_impute_static(self._h, x.data_ptr(), m.data_ptr(), out.data_ptr(), n, int(num_trials), int(seed),
+                                               int(row_offset), int(trial_offset), nz.data_ptr() if nz is not None else None,
+                                               tr.data_ptr() if tr is not None else None, flags, self._stream())
+            _lib.check(rc, "dp_impute_static")
+            return out, tr
         ws = self._workspace(n * num_trials)
         with torch.cuda.device(self.device):
             rc = self.lib.dp_impute(self._h, x.data_ptr(), m.data_ptr(), out.data_ptr(), n, int(num_trials), int(seed),
                                     int(row_offset), int(trial_offset), nz.data_ptr() if nz is not None else None,
-                                    tr.data_ptr() if tr is not None else None,
-                                    (_lib.DP_ACCUMULATE if accumulate else 0) | (0 if final_level else _lib.DP_NO_FINAL_LEVEL),
+                                    tr.data_ptr() if tr is not None else None, flags,
                                     ws.data_ptr(), ws.numel(), self._stream())
         _lib.check(rc, "dp_impute")
         return out, tr

@@ -112,6 +112,23 @@ int dp_impute(dp_plan* plan, const float* x_obs, const uint8_t* mask, float* out
               void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * dp_impute for callers that cannot allocate (code under HIP graph capture, tight serving loops that impute a few rows per
+ * request, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and same results, bit for
+ * bit, as dp_impute -- minus the workspace: the sampler state and activations live in a file-scope __device__ array of
+ * DP_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.  The call makes no hipMalloc /
+ * hipFree / other allocating call (device set-up, including the look-up of the array's per-device address, happens in
+ * dp_plan_create).  Limit: n_rows * num_trials chains must satisfy dp_workspace_bytes(plan, chains) <=
+ * DP_STATIC_SCRATCH_BYTES (2 816 chains at d_in = 256, hid = 1024, bf16; 3 840 at d_in = 9); larger calls are rejected with
+ * DP_EWORKSPACE.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads, two plans) race; serialise them on one stream.  Nothing needs to start at zero except the padded network
+ * input, which every call clears itself.
+ */
+#define DP_STATIC_SCRATCH_BYTES ((size_t)32 << 20)
+int dp_impute_static(dp_plan* plan, const float* x_obs, const uint8_t* mask, float* out,
+                     int64_t n_rows, int num_trials, uint64_t seed, uint64_t row_offset, int trial_offset,
+                     const float* noise, float* trace, int flags, void* stream);
+
+/*
  * One denoiser evaluation D(x, sigma) for a batch-wide scalar sigma.
  * Replaces: Precond.forward(x, sigma) with 0-dim sigma (model.py:148-165), i.e. the `net(x_hat, t_hat)`
  * calls at diffusion_utils.py:99,105.
