@@ -12,6 +12,11 @@ the shard length once the GPU is full).  Inputs are resident in HBM before the t
 Weak scaling: every rank takes its own `--rows` rows (global row offsets keep the Philox noise
 shard-invariant) and the per-step all-gather of the trial means is inside the timed region.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: before anything touches
+the GPU it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
+flags>` as a child process, passes rank 0's JSON line through and exits with the child's code (a process that has
+initialised the GPU is never re-executed).  `--config adult|news|synth1m|synth10m` selects the BASELINE.json shape.
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 256x256-tile bf16 MFMA
 GEMM that runs mlp.0 / mlp.2 / mlp.4): algorithmic FLOPs per launch / in-situ average launch
 duration from HIP events recorded on the launch stream during the timed steps (dp_plan_profile).
@@ -67,6 +72,19 @@ def cpu_baseline(d, hid, S, R, T, rows, budget_note):
             "row_trials_per_s": row_trials_per_s}
 
 
+def csrc_sha() -> str:
+    """sha256 over the kernel sources: PMC_TRAFFIC.json is stamped with it (tools/pmc_summary.py --stamp) so counters
+    measured on other kernels are never reported as this build's."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "diffputer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel: str, rows_per_launch: int):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE passes of their own, corrected as MI355X_MICROARCH.md §HBM prescribes; tools/pmc_summary.py).  Counters
@@ -76,6 +94,8 @@ def pmc_traffic(kernel: str, rows_per_launch: int):
         with open(path) as f:
             d = json.load(f)
         e = d.get(kernel) or d[kernel.replace("<true, 0>", "<true, false>")]
+        if d.get("_csrc_sha") != csrc_sha():
+            return None, f"PMC_TRAFFIC.json was collected on other kernel sources (sha {d.get('_csrc_sha')}, this build {csrc_sha()}): re-run the --pmc passes"
         if int(d.get("_rows_per_launch", 0)) != int(rows_per_launch):
             return None, f"PMC_TRAFFIC.json is for {d.get('_rows_per_launch')} rows per launch"
         return e["traffic_bytes"], "PMC_TRAFFIC.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, L2 fabric side (Infinity-Cache hits included)"
@@ -83,17 +103,63 @@ def pmc_traffic(kernel: str, rows_per_launch: int):
         return None, "no PMC summary on file"
 
 
+CONFIGS = {   # BASELINE.json configs -> (rows per GPU per step, cols, trials, what it stands for)
+    "synth10m": (32768, 256, 10, "BASELINE configs[4]: synthetic 10M x 256 table"),
+    "synth1m": (125000, 64, 10, "BASELINE configs[3]: synthetic 1M x 64 table, one of 8 row shards"),
+    "news": (27750, 51, 50, "BASELINE configs[2]: news-shaped table (27 750 train rows, 45 numeric + 6 binary-digit columns, synthetic stand-in)"),
+    "adult": (22792, 34, 20, "BASELINE configs[1]: adult-shaped table (22 792 train rows, 6 numeric + 28 binary-digit columns, synthetic stand-in), E-step of one EM iteration"),
+}
+
+
+class StandInPlan:
+    """--standin (tests only, never a measurement): a plan that does no sampling -- trial t of global row r "imputes"
+    r + t/64 -- so the launcher, the rank wiring and the collectives can run on CPU ranks over gloo."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def impute_sum(self, x_obs, mask, num_trials, *, seed=0, row_offset=0, trial_offset=0, out=None, accumulate=False):
+        rows = torch.arange(row_offset, row_offset + x_obs.shape[0], dtype=torch.float32, device=self.device)[:, None]
+        add = sum(rows + (trial_offset + t) / 64.0 for t in range(num_trials)).expand_as(out)
+        out.copy_(out + add if accumulate else add)
+        return out, None
+
+    def gemm_rows(self, n):
+        return n
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script under torch.distributed.run as a CHILD process (this process has not touched the GPU
+    and never will), pass the child's stdout through, return its exit code (non-zero if any rank failed)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("[bench] starting ranks: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=32768, help="rows of the table per GPU per step")
-    ap.add_argument("--cols", type=int, default=256)
+    ap.add_argument("--config", default="synth10m", choices=sorted(CONFIGS), help="BASELINE.json shape (rows/cols/trials defaults)")
+    ap.add_argument("--rows", type=int, default=None, help="rows of the table per GPU per step")
+    ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--hid", type=int, default=1024)
     ap.add_argument("--num-steps", type=int, default=50)
     ap.add_argument("--resample", type=int, default=20)
-    ap.add_argument("--trials", type=int, default=10)
+    ap.add_argument("--trials", type=int, default=None)
+    ap.add_argument("--standin", action="store_true", help="tests only: CPU ranks over gloo with a plan that does no sampling")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--max-chains", type=int, default=1 << 16)
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample (0 = skip)")
@@ -101,28 +167,44 @@ def main():
     ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
     ap.add_argument("--m-chunk", type=int, default=None, help="rows per wide-layer GEMM launch (dp_tune m_chunk; 0 = whole batch)")
     a = ap.parse_args()
+    preset = CONFIGS[a.config]
+    a.rows = preset[0] if a.rows is None else a.rows
+    a.cols = preset[1] if a.cols is None else a.cols
+    a.trials = preset[2] if a.trials is None else a.trials
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))                # nothing above this line initialises the GPU
+
+    if min(a.rows, a.cols, a.trials, a.steps) < 1 or a.warmup < 0:
+        raise SystemExit("--rows, --cols, --trials and --steps must be >= 1, --warmup >= 0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if a.standin:
+        dev, backend = torch.device("cpu"), "gloo"
+    else:
+        torch.cuda.set_device(local_rank)
+        dev, backend = torch.device("cuda", local_rank), "nccl"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({} if a.standin else {"device_id": dev}))
 
     d, hid, S, R, T = a.cols, a.hid, a.num_steps, a.resample, a.trials
     folded = a.dtype == "bf16" and not a.no_fold
-    from diffputer_amd import _lib
-    _lib.check(_lib.load().dp_tune(b"fold_proj", 0 if a.no_fold else 1), "dp_tune")
-    if a.m_chunk is not None:
-        _lib.check(_lib.load().dp_tune(b"m_chunk", a.m_chunk), "dp_tune")
-    # random-init weights of the reference architecture (throughput is weight-independent), synthetic table shard
-    sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(d, hid, seed=1, gain=1.0).items()}
-    plan = SamplerPlan(sd, num_steps=S, n_resample=R, dtype=a.dtype, device=dev)
+    if a.standin:
+        plan = StandInPlan(dev)
+        a.no_profile, a.cpu_rows = True, 0
+    else:
+        from diffputer_amd import _lib
+        _lib.check(_lib.load().dp_tune(b"fold_proj", 0 if a.no_fold else 1), "dp_tune")
+        if a.m_chunk is not None:
+            _lib.check(_lib.load().dp_tune(b"m_chunk", a.m_chunk), "dp_tune")
+        # random-init weights of the reference architecture (throughput is weight-independent), synthetic table shard
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(d, hid, seed=1, gain=1.0).items()}
+        plan = SamplerPlan(sd, num_steps=S, n_resample=R, dtype=a.dtype, device=dev)
     X, mask = synth.make_table(a.rows, d, seed=1234 + rank)
     Xd = torch.from_numpy(X).to(dev)
     md = torch.from_numpy(mask).to(dev)
@@ -138,7 +220,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not a.standin:
+            torch.cuda.synchronize(dev)
 
     for w in range(a.warmup):
         one_step(-1 - w)
@@ -158,8 +241,16 @@ def main():
 
     assert torch.isfinite(out).all(), "non-finite imputations"
     obs = ~md
-    if world == 1:
+    if world == 1 and not a.standin:
         assert torch.allclose(out[obs], Xd[obs], rtol=1e-6, atol=0), "observed cells must pass through"
+    if world > 1:
+        assert tuple(out.shape) == (n_total, d), "the gathered table must hold every rank's rows"
+    ranks_seen = world
+    if world > 1:                                             # what the process group itself reports, counted by a collective
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == dist.get_world_size() == world
 
     rows_per_s = n_total * a.steps / dt
     nfe = nfe_per_chain(S, R)
@@ -175,18 +266,23 @@ def main():
         "metric": "imputed rows/sec (E-step, 50 steps x 10 trials)",
         "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[4]: synthetic 10M x {d} table, S={S} x R={R} x Heun, T={T} trials, "
+        "dtype": a.dtype, "data": "standin (no sampling: launcher/collective test only, NOT a measurement)" if a.standin else "synthetic",
+        "ranks": ranks_seen, "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else "none (single process)"),
+        "config": {"workload": f"{preset[3]}, {d} cols, S={S} x R={R} x Heun, T={T} trials, "
                                f"hid={hid}; each step = full E-step of a {a.rows}-row shard per GPU (MCAR 30%, random-init weights)",
+                   "name": a.config,
                    "rows_per_step_per_gpu": a.rows, "cols": d, "num_steps": S, "n_resample": R, "num_trials": T, "hid": hid,
                    "chains_per_call": min(a.max_chains, a.rows * T), "wide_gemm_rows_per_launch": plan.gemm_rows(min(a.max_chains, a.rows * T)),
                    "parallelism": f"row-shard x{world}, all-gather of trial means"},
         "row_trials_per_s": rows_per_s * T, "denoiser_row_evals_per_s": rows_per_s * T * nfe,
-        "whole_path": {"tflops_per_gpu": whole_tflops, "frac_of_mfma_peak": whole_tflops / peak,
-                       "flops_per_row": T * nfe * fl_row_eval,
-                       "note": "reference FLOP model 4DH+16H^2 per row-evaluation; executed_* counts the GEMMs as launched "
-                               "(proj folded into mlp.0: same function, fewer FLOPs)" if folded else "reference FLOP model",
-                       "executed_tflops_per_gpu": exec_tflops, "executed_frac_of_mfma_peak": exec_tflops / peak,
+        # primary figures = FLOPs the GEMM kernels execute; the reference's FLOP model (5 layers, 4DH + 16H^2 per
+        # row-evaluation) is the secondary "model_equivalent" pair: with proj folded into mlp.0 the same function costs fewer FLOPs
+        "whole_path": {"tflops_per_gpu": exec_tflops, "frac_of_mfma_peak": exec_tflops / peak,
+                       "executed_flops_per_row": T * nfe * exec_row_eval,
+                       "model_equivalent_tflops_per_gpu": whole_tflops, "model_equivalent_frac_of_mfma_peak": whole_tflops / peak,
+                       "model_flops_per_row": T * nfe * fl_row_eval,
+                       "note": "tflops_per_gpu counts the GEMMs as launched (padded widths; proj folded into mlp.0 = 4 GEMMs per "
+                               "evaluation); model_equivalent_* prices the same rows/s with the reference's 5-layer FLOP model",
                        "proj_folded_into_mlp0": folded},
     }
 
@@ -225,6 +321,9 @@ def main():
                                     "avg_launch_ms": ms[6] / cnt[6], "alg_bytes_per_launch": step_bytes}
         result["kernels"] = per
 
+    if a.standin:                                             # never a throughput claim
+        result["value"] = result["row_trials_per_s"] = result["denoiser_row_evals_per_s"] = 0.0
+        del result["whole_path"]
     if rank == 0 and a.gpus == 1 and a.cpu_rows > 0:
         result["cpu_baseline"] = cpu_baseline(d, hid, S, R, T, a.cpu_rows, "")
     elif rank == 0:

@@ -229,6 +229,29 @@ def test_run_em_world_size_2_gloo_one_trainer_one_writer(tmp_path):
     assert os.listdir(tmp_path / "0") == ["model.pt"]
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command form) launches two ranks itself
+    under torch.distributed.run, and rank 0's JSON line reports what the process group saw.  CPU ranks over gloo with
+    bench.py's stand-in plan (no sampling): this covers the launcher, the rank wiring, the row-offset arithmetic and the
+    all-gather inside the timed step -- the RCCL run itself is the driver's."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--standin", "--steps", "2", "--warmup", "1",
+                        "--rows", "37", "--cols", "5", "--trials", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["backend"] == "gloo" and j["steps"] == 2 and j["warmup"] == 1
+    assert j["value"] == 0.0 and "standin" in j["data"] and j["scaling"] == "weak"
+    # a failing rank makes the launcher exit non-zero
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--standin", "--rows", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
 def test_prep_helpers_match_reference():
     """evalmetrics.mean_std / mae_rmse against the reference's mean_std (dataset.py:161-169) and get_eval (:171-206)
     run on 2 048 california rows (tools/make_prep_golden.py)."""
