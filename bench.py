@@ -188,7 +188,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dev, backend = torch.device("cuda", local_rank), "nccl"
     dist = None
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ                    # under torch.distributed.run, also with one rank: the RCCL
+    if use_dist:                                              # branch (init, all-gather, all-reduce) then runs on a 1-GPU box too
         import torch.distributed as dist
         dist.init_process_group(backend, **({} if a.standin else {"device_id": dev}))
 
@@ -213,12 +214,12 @@ def main():
 
     def one_step(step_idx):
         local = estep.impute_trials(plan, Xd, md, T, seed=1000 + step_idx, row_offset=row_offset, max_chains=a.max_chains)
-        if world > 1:
+        if use_dist:
             return estep.gather_rows(local, n_total)
         return local
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         if not a.standin:
             torch.cuda.synchronize(dev)
@@ -234,7 +235,7 @@ def main():
         out = one_step(k)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -243,10 +244,9 @@ def main():
     obs = ~md
     if world == 1 and not a.standin:
         assert torch.allclose(out[obs], Xd[obs], rtol=1e-6, atol=0), "observed cells must pass through"
-    if world > 1:
-        assert tuple(out.shape) == (n_total, d), "the gathered table must hold every rank's rows"
+    assert tuple(out.shape) == (n_total, d), "the (gathered) table must hold every rank's rows"
     ranks_seen = world
-    if world > 1:                                             # what the process group itself reports, counted by a collective
+    if use_dist:                                              # what the process group itself reports, counted by a collective
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
@@ -267,7 +267,7 @@ def main():
         "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "standin (no sampling: launcher/collective test only, NOT a measurement)" if a.standin else "synthetic",
-        "ranks": ranks_seen, "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else "none (single process)"),
+        "ranks": ranks_seen, "backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if use_dist else "none (single process)"),
         "config": {"workload": f"{preset[3]}, {d} cols, S={S} x R={R} x Heun, T={T} trials, "
                                f"hid={hid}; each step = full E-step of a {a.rows}-row shard per GPU (MCAR 30%, random-init weights)",
                    "name": a.config,
@@ -331,7 +331,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -12,14 +12,44 @@ import numpy as np
 
 
 def bits_for(num_categories: int) -> int:
-    """Digits of a categorical column with `num_categories` values (dataset.py:80); 0 for a single-valued column."""
-    return (int(num_categories) - 1).bit_length()
+    """Digits of a categorical column with `num_categories` values: `(n - 1).bit_length()` (dataset.py:80) -- except that
+    a single-valued column still gets ONE digit (always 0): the reference formats index 0 with '00b', which prints '0'
+    (dataset.py:82), and counts the digits it printed (:122).  Pinned by tests/golden/layout_mixed.npz."""
+    return max(1, (int(num_categories) - 1).bit_length())
+
+
+def category_index(data_values, values) -> np.ndarray:
+    """Category indices as `load_dataset` assigns them (dataset.py:39,77,83,110): every value goes through str(), and a
+    category's index is its rank of FIRST APPEARANCE in the full table's column (`data.csv`), not its sorted rank.
+    data_values: the column of the full table; values: the column of the split to encode.  -> [N] int64."""
+    order: dict = {}
+    for v in np.asarray(data_values).astype(str):
+        order.setdefault(v, len(order))
+    try:
+        return np.asarray([order[v] for v in np.asarray(values).astype(str)], dtype=np.int64)
+    except KeyError as e:
+        raise ValueError(f"category {e.args[0]!r} does not occur in the full table") from None
+
+
+def load_mixed(data_cols, split_cols, mask, num_col_idx, cat_col_idx):
+    """The mixed-table branch of `load_dataset` (dataset.py:36-49, 70-157) on columns already read from the CSVs.
+    data_cols / split_cols: one array per ORIGINAL column of data.csv / of the split (train.csv or test.csv), indexable
+    by original column index (a list, or a dict keyed by index); mask [N, n_original_columns] bool, True = missing.
+    -> (X [N, D] float32, extended mask [N, D] bool, cat_idx [N, c] int64, cat_bin_num [c]); numeric columns first in
+    num_col_idx order, then each categorical column's digits in cat_col_idx order; the target column is dropped."""
+    num = np.stack([np.asarray(split_cols[j]).astype(np.float32) for j in num_col_idx], axis=1)
+    cat_idx = np.stack([category_index(data_cols[j], split_cols[j]) for j in cat_col_idx], axis=1)
+    n_cat = [len(set(np.asarray(data_cols[j]).astype(str))) for j in cat_col_idx]
+    X, bins = encode_table(num, cat_idx, n_cat)
+    mask = np.asarray(mask).astype(bool)
+    m = extend_mask(np.concatenate([mask[:, list(num_col_idx)], mask[:, list(cat_col_idx)]], axis=1), len(num_col_idx), bins)
+    return X, m, cat_idx, bins
 
 
 def encode_bits(cat_idx: np.ndarray, num_bits: int) -> np.ndarray:
     """[N] category indices -> [N, num_bits] float32 digits, most significant first (the '0{n}b' format of dataset.py:82)."""
     idx = np.asarray(cat_idx, dtype=np.int64)
-    if idx.size and (idx.min() < 0 or idx.max() >= (1 << num_bits) and num_bits > 0 or (num_bits == 0 and idx.max() > 0)):
+    if idx.size and (idx.min() < 0 or idx.max() >= (1 << num_bits)):
         raise ValueError(f"category index out of range for {num_bits} bits")
     shifts = np.arange(num_bits - 1, -1, -1, dtype=np.int64)
     return ((idx[:, None] >> shifts[None, :]) & 1).astype(np.float32)

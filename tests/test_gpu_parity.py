@@ -184,7 +184,7 @@ def _trajectory(name, dtype):
     return g, out.cpu().numpy(), tr[:, 0].cpu().numpy(), t
 
 
-@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16", "impute_D9_H64_S50_N8",
+@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16", "impute_D51_H256_S10_N16", "impute_D9_H64_S50_N8",
                                   "impute_D9_H1024_S50_N16", "impute_D64_H1024_S10_N32"])
 def test_impute_f32_per_step(name, fold):
     """north_star: per-step outputs within 1e-3 relative in fp32, identical noise."""
@@ -463,6 +463,29 @@ def test_no_final_level_takes_no_draw_past_the_replay_buffer():
     p.close()
 
 
+def test_mstep_loss_and_gradient_on_device_match_reference():
+    """the M-step's loss and gradients, computed by PyTorch-ROCm on the device (north_star: "PyTorch-ROCm
+    owns tensors and the M-step"), against the reference-generated fixture; float32 GEMMs on the GPU sum in another order
+    than the CPU's, hence 1e-4 here where the CPU mirror holds 1e-5 (tests/test_host_logic.py)."""
+    from test_host_logic import check_mstep
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        check_mstep(load_golden("mstep_D12_H64"), DEV, 1e-4)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+def test_device_mean_std_on_reference_mixed_table():
+    """a9 on the device: dp_masked_mean_std over the mixed table that the reference's load_dataset built
+    (tests/golden/layout_mixed.npz), against the reference's mean_std -- bit columns and the constant column included."""
+    from diffputer_amd import prep
+    g = load_golden("layout_mixed")
+    mean, std = prep.masked_mean_std(torch.from_numpy(g["train_X"]).to(DEV), torch.from_numpy(g["train_mask"]).to(DEV))
+    assert np.allclose(mean.cpu().numpy(), g["mean"], rtol=1e-5, atol=0), np.abs(mean.cpu().numpy() - g["mean"]).max()
+    assert np.allclose(std.cpu().numpy(), g["std"], rtol=1e-5, atol=1e-7)
+
+
 def test_device_prep_and_scoring_golden():
     """masked mean/std and MAE/RMSE reductions on the device against the reference's numbers."""
     from diffputer_amd import prep
@@ -662,3 +685,98 @@ def test_full_config_properties():
     print(f"bf16 vs f32 at the bench config: mean |d| {float(dlt.mean()):.3e}, p99.9 {float(dlt.quantile(0.999)):.3e}, "
           f"max {float(dlt.max()):.3e}, field std {spread:.3f}")
     assert float(dlt.mean()) < 1.2e-4 and float(dlt.quantile(0.999)) < 6e-4 and float(dlt.max()) < 1e-3
+
+
+def test_news_config_properties():
+    """BASELINE configs[2] at its stated width and depth: D = 51 (45 numeric + 2 x 3 binary digits: not a multiple of 4, so
+    the step kernels run one cell per thread and the GEMMs pad K and N to 64), H = 1024, S = 50, R = 20, **T = 50**
+    (main.py:27 --num_trials 50), on 640 rows (32 000 chains) of the 27 750.  The oracle cannot reach this in seconds, so:
+    properties.  (1) the trial axis shards: the sums over trials [0, 25) and [25, 50) (trial_range, what shard="trials"
+    gives each rank) add up to the one-call sum, up to the float32 rounding of regrouping the trial sum; (2) shard="trials"
+    and shard="rows" E-steps agree; (3) the E-step mean of 50 trials is reproducible per seed and passes observed cells
+    through; (4) single trials differ from each other (they are independent chains) while their mean's spread shrinks."""
+    from diffputer_amd import estep
+    d, hid, S, R, n, T = 51, 1024, 50, 20, 640, 50
+    sd = synth.make_weights(d, hid, 7, 1.0)
+    X, mask = synth.make_table(n, d, seed=777)
+    Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(mask).to(DEV)
+    p = _plan(sd, S, R, "bf16")
+    full = estep.impute_trials(p, Xd, md, T, seed=5)                               # mean over 50 trials
+    lo = estep.impute_trials(p, Xd, md, T, seed=5, trial_range=(0, 25))            # sums
+    hi = estep.impute_trials(p, Xd, md, T, seed=5, trial_range=(25, 50))
+    assert torch.isfinite(full).all()
+    assert torch.allclose((lo + hi) / T, full, rtol=2e-6, atol=2e-6), float(((lo + hi) / T - full).abs().max())
+    obs = ~md
+    assert torch.allclose(full[obs], Xd[obs], rtol=1e-6, atol=0), "observed cells must pass through the 50-trial mean"
+    again = estep.impute_trials(p, Xd, md, T, seed=5)
+    assert torch.equal(full, again)
+    one_a = estep.impute_trials(p, Xd, md, T, seed=5, trial_range=(3, 4))
+    one_b = estep.impute_trials(p, Xd, md, T, seed=5, trial_range=(4, 5))
+    miss = md
+    assert float((one_a - one_b)[miss].abs().mean()) > 1e-3, "trials must be independent chains"
+    # spread of a single trial around the 50-trial mean vs spread of a 25-trial mean around it: ~ sqrt(25) smaller
+    s1 = float((one_a - full)[miss].std())
+    s25 = float((lo / 25 - full)[miss].std())
+    assert s25 < 0.4 * s1, (s1, s25)
+    p.close()
+
+    from diffputer_amd.model import MLPDiffusion, Model
+    model = Model(denoise_fn=MLPDiffusion(d, hid), hid_dim=d).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = model.denoise_fn_D
+    by_rows = estep.e_step(net, Xd[:128], md[:128], T, S, DEV, seed=5, dtype="bf16")
+    by_trials = estep.e_step(net, Xd[:128], md[:128], T, S, DEV, seed=5, dtype="bf16", shard="trials")
+    assert torch.allclose(by_rows, by_trials, rtol=2e-6, atol=2e-6)
+    assert torch.allclose(by_rows, full[:128], rtol=2e-6, atol=2e-6)               # row subsets do not change a row's result
+
+
+def test_adult_config_properties():
+    """BASELINE configs[1] at its stated width: D = 34 (6 numeric + 28 binary digits), H = 1024, S = 50, R = 20, T = 20, on
+    512 rows of the 22 792: sharding / batching invariance bit for bit, pass-through, and bf16 held to the float32 plan on
+    the same Philox draws (same bound as the D = 256 case)."""
+    d, hid, S, R, n, T = 34, 1024, 50, 20, 512, 20
+    sd = synth.make_weights(d, hid, 8, 1.0)
+    X, mask = synth.make_table(n, d, seed=888)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    p = _plan(sd, S, R, "bf16")
+    whole, _ = p.impute_sum(x_obs, mask, T, seed=21)
+    acc = torch.zeros(n, d, device=DEV)
+    for r0, r1 in ((0, 200), (200, n)):
+        for t0, t1 in ((0, 7), (7, 20)):
+            p.impute_sum(x_obs[r0:r1], mask[r0:r1], t1 - t0, seed=21, row_offset=r0, trial_offset=t0, out=acc[r0:r1], accumulate=t0 > 0)
+    assert torch.equal(acc, whole)
+    obs = torch.from_numpy(~mask).to(DEV)
+    assert torch.allclose(whole[obs], T * torch.from_numpy(x_obs).to(DEV)[obs], rtol=1e-6, atol=0)
+    got, _ = p.impute_sum(x_obs[:128], mask[:128], 2, seed=21)
+    p.close()
+    p32 = _plan(sd, S, R, "f32")
+    ref, _ = p32.impute_sum(x_obs[:128], mask[:128], 2, seed=21)
+    p32.close()
+    dlt = ((got - ref) / 2)[~obs[:128]].abs()
+    print(f"bf16 vs f32 at the adult config: mean |d| {float(dlt.mean()):.3e}, max {float(dlt.max()):.3e}")
+    assert float(dlt.mean()) < 1.2e-4 and float(dlt.max()) < 1e-3
+
+
+def test_million_row_pass_through_e_step():
+    """BASELINE configs[3] shape at full row count for one GPU: 1 048 576 rows x 64 columns through estep.e_step (call
+    planning: 16 calls of 65 536 chains), shortened to S = 3, R = 2, T = 1 so that it runs in seconds -- the row axis is
+    what is at size here.  Properties: every row is written, observed cells pass through bit-exactly, a row's result does
+    not depend on which call it fell into (recomputed for rows straddling call boundaries)."""
+    from diffputer_amd import estep
+    from diffputer_amd.model import MLPDiffusion, Model
+    d, hid, S, n = 64, 256, 3, 1 << 20
+    sd = synth.make_weights(d, hid, 9, 1.0)
+    model = Model(denoise_fn=MLPDiffusion(d, hid), hid_dim=d).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g = torch.Generator(device=DEV).manual_seed(3)
+    X = torch.randn(n, d, device=DEV, generator=g) * 0.5
+    mask = torch.rand(n, d, device=DEV, generator=g) < 0.3
+    out = estep.e_step(model.denoise_fn_D, X, mask, 1, S, DEV, seed=77, dtype="bf16", n_resample=2)
+    assert tuple(out.shape) == (n, d) and bool(torch.isfinite(out).all())
+    assert torch.equal(out[~mask], X[~mask])
+    assert float(out[mask].abs().mean()) > 0
+    rows = torch.tensor([0, 65535, 65536, 65537, 524288, n - 1], device=DEV)
+    plan = estep.plan_for(model.denoise_fn_D, S, DEV, "bf16", 2)
+    for r in rows.tolist():
+        one = estep.impute_trials(plan, X[r:r + 1], mask[r:r + 1], 1, seed=77, row_offset=r)
+        assert torch.equal(one[0], out[r]), r

@@ -252,6 +252,76 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode != 0
 
 
+def test_mixed_table_layout_matches_reference_load_dataset():
+    """a9 pinned to the reference: tests/golden/layout_mixed.npz holds what `dataset.load_dataset` (dataset.py:10-159) and
+    `mean_std` made of a small synthetic mixed table with interleaved numeric / categorical / target columns
+    (tools/make_layout_golden.py).  layout.load_mixed must reproduce train_X / test_X, the extended masks, the category
+    indices and cat_bin_num exactly -- including first-appearance category order, integer-valued categories mapped through
+    str(), and the single-valued column that still gets one digit."""
+    from conftest import load_golden
+    from diffputer_amd import layout
+    from diffputer_amd.evalmetrics import mean_std
+    g = load_golden("layout_mixed")
+    ni, ci = list(g["num_col_idx"]), list(g["cat_col_idx"])
+    data_cols = {j: g[f"data_num_{j}"] for j in ni} | {j: g[f"data_cat_{j}"] for j in ci}
+    for tag in ("train", "test"):
+        cols = {j: g[f"{tag}_num_{j}"] for j in ni} | {j: g[f"{tag}_cat_{j}"] for j in ci}
+        X, m, cat_idx, bins = layout.load_mixed(data_cols, cols, g[f"{tag}_mask0"], ni, ci)
+        assert X.dtype == np.float32 and np.array_equal(X, g[f"{tag}_X"])
+        assert m.dtype == bool and np.array_equal(m, g[f"{tag}_mask"])
+        assert np.array_equal(cat_idx, g[f"{tag}_cat_idx"]) and np.array_equal(bins, g["cat_bin_num"])
+        assert np.array_equal(layout.decode_bits(X[:, len(ni):], bins), cat_idx)
+    assert list(g["cat_bin_num"]) == [4, 3, 1, 1]
+    X, m, _, _ = layout.load_mixed(data_cols, {j: g[f"train_num_{j}"] for j in ni} | {j: g[f"train_cat_{j}"] for j in ci},
+                                   g["train_mask0"], ni, ci)
+    mean, std = mean_std(X, m)
+    assert np.allclose(mean, g["mean"], rtol=1e-6, atol=0) and np.allclose(std, g["std"], rtol=1e-6, atol=1e-12)
+    with pytest.raises(ValueError):
+        layout.category_index(["a", "b"], ["c"])
+
+
+def mstep_loss_and_grads(g, device):
+    """diffputer_amd.model.Model on `device` with the fixture's weights and its two Gaussian draws replayed:
+    (loss, per-cell loss, gradients by short name).  Shared with the GPU test."""
+    sd = synth.make_weights(int(g["d_in"]), int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+    m = dmodel.Model(dmodel.MLPDiffusion(int(g["d_in"]), int(g["hid"])), hid_dim=int(g["d_in"])).to(device)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.train()
+    x = torch.from_numpy(g["x"]).to(device)
+    zs, zn = torch.from_numpy(g["z_sigma"]).to(device), torch.from_numpy(g["z_noise"]).to(device)
+    saved = (torch.randn, torch.randn_like)
+    torch.randn = lambda *a, **k: zs.clone()
+    torch.randn_like = lambda t, **k: zn.clone()
+    try:
+        percell = m.loss_fn(m.denoise_fn_D, x).detach()
+        loss = m(x)
+    finally:
+        torch.randn, torch.randn_like = saved
+    loss.backward()
+    grads = {k[len(synth.CKPT_PREFIX):]: v.grad for k, v in m.named_parameters()}
+    return loss.detach(), percell, grads
+
+
+def check_mstep(g, device, rtol):
+    loss, percell, grads = mstep_loss_and_grads(g, device)
+    assert abs(float(loss) - float(g["loss"])) <= rtol * float(g["loss"]), (float(loss), float(g["loss"]))
+    pc = percell.cpu().numpy()
+    assert np.all(np.abs(pc - g["percell"]) <= rtol * np.maximum(np.abs(g["percell"]), float(np.abs(g["percell"]).mean())))
+    for name in ("proj.weight", "mlp.2.weight", "time_embed.0.weight", "mlp.6.bias"):
+        ref = g["grad__" + name]
+        got = grads[name].cpu().numpy()
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) <= rtol * scale, (name, float(np.abs(got - ref).max()), scale)
+
+
+def test_mstep_loss_and_gradient_match_reference():
+    """f1 pinned: tests/golden/mstep_D12_H64.npz holds the reference's Model.forward (model.py:171-181 -> EDMLoss,
+    diffusion_utils.py:200-215 -> Precond.forward with per-row sigma) and its gradients on one batch with replayed draws
+    (tools/make_mstep_golden.py).  The mirrored modules reproduce loss, per-cell loss and gradients to 1e-5 relative."""
+    from conftest import load_golden
+    check_mstep(load_golden("mstep_D12_H64"), "cpu", 1e-5)
+
+
 def test_prep_helpers_match_reference():
     """evalmetrics.mean_std / mae_rmse against the reference's mean_std (dataset.py:161-169) and get_eval (:171-206)
     run on 2 048 california rows (tools/make_prep_golden.py)."""
@@ -297,14 +367,14 @@ def test_mixed_table_layout():
     from diffputer_amd import layout
     rng = np.random.default_rng(5)
     n_cat = [9, 16, 7, 2, 42, 1]                                     # adult's column sizes among them
-    assert [layout.bits_for(n) for n in n_cat] == [4, 4, 3, 1, 6, 0]
+    assert [layout.bits_for(n) for n in n_cat] == [4, 4, 3, 1, 6, 1]  # a single-valued column still prints one digit: '00b' -> '0'
     N, k = 50, 3
     num = rng.standard_normal((N, k)).astype(np.float32)
     cat = np.stack([rng.integers(0, n, N) for n in n_cat], axis=1)
     X, bins = layout.encode_table(num, cat, n_cat)
-    assert X.dtype == np.float32 and X.shape == (N, k + 18) and list(bins) == [4, 4, 3, 1, 6, 0]
+    assert X.dtype == np.float32 and X.shape == (N, k + 19) and list(bins) == [4, 4, 3, 1, 6, 1]
     for r in range(N):
-        want = "".join(format(int(cat[r, j]), f"0{b}b") if b else "" for j, b in enumerate(bins))
+        want = "".join(format(int(cat[r, j]), "0" + str((n - 1).bit_length()) + "b") for j, n in enumerate(n_cat))   # dataset.py:80-82
         assert "".join(str(int(v)) for v in X[r, k:]) == want
     assert np.array_equal(X[:, :k], num)
     mask = rng.random((N, k + len(n_cat))) < 0.3

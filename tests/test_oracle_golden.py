@@ -79,7 +79,7 @@ def _run_impute(name, noise=None):
     return g, out, np.stack(trace)
 
 
-@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16",
+@pytest.mark.parametrize("name", ["impute_D9_H64_S5_N8", "impute_D34_H256_S10_N16", "impute_D51_H256_S10_N16",
                                   "impute_D9_H64_S50_N8"])
 def test_impute_mask_trajectory(name):
     g, out, trace = _run_impute(name)

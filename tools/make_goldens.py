@@ -224,6 +224,13 @@ def gold_impute():
     save("impute_D64_H1024_S10_N32", **g)
 
 
+def gold_impute_news():
+    """news stand-in width (45 numeric + 3 + 3 binary-digit columns, D = 51 -- not a multiple of 4, so the
+    step kernels run one cell per thread and the GEMMs pad K and N to 64)."""
+    g, _ = run_impute(51, 256, 10, 16, wseed=550, gain=2.0, nseed=551, xseed=552)
+    save("impute_D51_H256_S10_N16", **g)
+
+
 def gold_estep():
     """The E-step driver of main.py:160-190 for T=3 trials: per-trial impute_mask, final blend,
     stack().mean(0).  Stored in the sampler's x/2 scale (before the *2 of main.py:190)."""
@@ -276,7 +283,7 @@ def gold_variants():
 
 
 ALL = {"variants": gold_variants, "schedule": gold_schedule, "embedding": gold_embedding, "denoiser": gold_denoiser,
-       "sample_step": gold_sample_step, "impute": gold_impute, "estep": gold_estep}
+       "sample_step": gold_sample_step, "impute": gold_impute, "impute_news": gold_impute_news, "estep": gold_estep}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
