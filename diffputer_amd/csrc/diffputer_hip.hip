@@ -11,6 +11,7 @@
 #include "dp_embed.h"
 #include "dp_gemm_bf16.h"
 #include "dp_gemm_bf16_pp.h"
+#include "dp_gemm_bf16_ws.h"
 #include "dp_gemm_f32.h"
 #include "dp_philox.h"
 #include "dp_prep.h"
@@ -87,6 +88,7 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
 static std::atomic<int> g_gemm_variant{2};
 static std::atomic<int> g_fold_proj{1};
 static std::atomic<int> g_m_chunk{32768};  // "m_chunk": rows per launch of the wide layers in bf16 plans (0 = whole batch), see eval_F
+static std::atomic<int> g_ws_gemm{1};      // "ws_gemm": 1 = weight-stationary kernel for layers with K <= 256 and N % 256 == 0 (bf16 plans)
 static std::atomic<int> g_fuse_mid{1};     // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 static inline int tune(const std::atomic<int>& v) { return v.load(std::memory_order_relaxed); }
 
@@ -158,6 +160,38 @@ static int launch_bf16_cfg(const bf16_t* A, const bf16_t* W, const float* bias, 
     return DP_OK;
 }
 
+// K <= 256: the weight-stationary kernel (dp_gemm_bf16_ws.h)
+static int launch_bf16_ws(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
+                          int act, int out_f32, hipStream_t st) {
+    const DeviceState* ds = device_state();
+    if (!ds) return DP_EHIP;
+    const int nbn = N / WS_BN;
+    const int64_t n_rg64 = M / WS_ROWS;
+    if (n_rg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM too tall");
+    const int n_rg = (int)n_rg64;
+    // one workgroup per CU at most, a whole number of workgroups per column tile, none without work
+    const int slots = std::max(1, std::min(ds->num_cus / nbn, ceil_div(n_rg, 8)));
+    const int grid = slots * nbn;
+#define DP_GO(KT)                                                                                                   \
+    do {                                                                                                            \
+        const int lds = ws_lds_bytes(KT);                                                                           \
+        if (act && !out_f32) hipLaunchKernelGGL((k_gemm_bf16_ws<KT, true, false>), dim3(grid), dim3(WS_THREADS), lds, st, A, W, bias, out, ldo, nbn, n_rg); \
+        else if (!act && !out_f32) hipLaunchKernelGGL((k_gemm_bf16_ws<KT, false, false>), dim3(grid), dim3(WS_THREADS), lds, st, A, W, bias, out, ldo, nbn, n_rg); \
+        else if (!act && out_f32) hipLaunchKernelGGL((k_gemm_bf16_ws<KT, false, true>), dim3(grid), dim3(WS_THREADS), lds, st, A, W, bias, out, ldo, nbn, n_rg); \
+        else hipLaunchKernelGGL((k_gemm_bf16_ws<KT, true, true>), dim3(grid), dim3(WS_THREADS), lds, st, A, W, bias, out, ldo, nbn, n_rg); \
+    } while (0)
+    switch (K / 64) {
+        case 1: DP_GO(1); break;
+        case 2: DP_GO(2); break;
+        case 3: DP_GO(3); break;
+        case 4: DP_GO(4); break;
+        default: return fail(DP_EINVAL, "weight-stationary GEMM needs K <= 256");
+    }
+#undef DP_GO
+    DP_LAUNCH_CHECK("k_gemm_bf16_ws");
+    return DP_OK;
+}
+
 // One-time set-up of device `dev` (current on the calling thread): see DeviceState.
 static int ensure_device_ready(int dev) {
     std::lock_guard<std::mutex> lock(g_dev_mutex);
@@ -180,6 +214,13 @@ static int ensure_device_ready(int dev) {
     DP_ATTR4(256, 256, 2, 4);
     DP_ATTR4(256, 64, 4, 1);
 #undef DP_ATTR4
+#define DP_ATTR_WS(KT)                                                                            \
+    DP_ATTR((k_gemm_bf16_ws<KT, true, false>), ws_lds_bytes(KT));                                 \
+    DP_ATTR((k_gemm_bf16_ws<KT, false, false>), ws_lds_bytes(KT));                                \
+    DP_ATTR((k_gemm_bf16_ws<KT, true, true>), ws_lds_bytes(KT));                                  \
+    DP_ATTR((k_gemm_bf16_ws<KT, false, true>), ws_lds_bytes(KT))
+    DP_ATTR_WS(1); DP_ATTR_WS(2); DP_ATTR_WS(3); DP_ATTR_WS(4);
+#undef DP_ATTR_WS
 #undef DP_ATTR
     // this device's copy of the scratch array: from here on host code uses d.scratch, never the array's name
     void* sp = nullptr;
@@ -194,6 +235,8 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
     if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
+        if (N % 256 == 0 && K <= 256 && tune(g_ws_gemm) && tune(g_gemm_variant) == 2)
+            return launch_bf16_ws((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) == 2)
             return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         if (N % 256 == 0)
@@ -774,6 +817,11 @@ int dp_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_variant")) {
         if (value < 1 || value > 2) return fail(DP_EINVAL, "gemm_variant must be 1 or 2");
         g_gemm_variant = value;
+        return DP_OK;
+    }
+    if (!strcmp(key, "ws_gemm")) {
+        if (value < 0 || value > 1) return fail(DP_EINVAL, "ws_gemm must be 0 or 1");
+        g_ws_gemm = value;
         return DP_OK;
     }
     if (!strcmp(key, "fuse_mid")) {

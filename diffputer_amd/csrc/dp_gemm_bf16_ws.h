@@ -1,0 +1,177 @@
+// Weight-stationary bf16 MFMA GEMM for the denoiser's SHALLOW Linear layers (K <= 256): the folded proj+mlp.0 layer
+// (model.py:102,105,126-128; K = d_in padded to 64) and, unfolded, proj itself.
+//
+//   out[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] )        A: activations [M, K], W: torch Linear weight [N, K]
+//
+// Why a third kernel: with K = 256 a 256x256 output tile is only four K-tiles deep, and k_gemm_bf16_pp spends as long in
+// its SiLU / store epilogue (exp + rcp per element, quarter rate) as in its K loop, with the matrix pipes idle meanwhile
+// (57 us per 32 768 x 2048 launch = 600 TFLOP/s).  Its two wave rows cannot drift apart to overlap one's epilogue with
+// the other's MFMAs: every phase ends in a workgroup barrier, because each wave stages operand pieces the others read.
+// Here nothing is shared after set-up:
+//   * the workgroup's whole W tile (256 columns x K <= 256: at most 128 KiB) is loaded into LDS ONCE (LDS-DMA, the XOR-
+//     swizzled image of k_gemm_bf16) and stays; a workgroup keeps its column tile for the whole launch (blocks b and b+8
+//     share an XCD, and with N = 2048 an XCD's 32 workgroups share one column tile, so W is read from HBM/L2 once per XCD);
+//   * a WAVE owns 32 rows x 256 columns (128 accumulator registers, as in the other kernels) of a "row group" and loads
+//     its activation fragments straight from global memory into registers (16 B per lane, each byte loaded once per
+//     workgroup; the next row group's fragments are requested as soon as the current ones have fed their last MFMA);
+//   * so after the single set-up barrier no wave waits for another: the eight waves run free, and on each SIMD one
+//     wave's epilogue (VALU) runs under its partner's MFMAs.  Waves 4-7 start half a row group late to set that up.
+// LDS reads: one ds_read_b128 of W per two MFMAs (512 B per MFMA, 50 % of the LDS read rate with all four SIMDs in their
+// K loops).  The accumulation order over k is that of k_gemm_bf16 (k-steps of 32, ascending), so results are bit-identical.
+#pragma once
+#include "dp_gemm_bf16.h"
+
+namespace dp {
+
+constexpr int WS_BN = 256, WS_ROWS = 32, WS_THREADS = 512;
+constexpr int WS_STAGE_WAVE = 2048;                              // epilogue transposer per wave (16 rows x 128 B)
+constexpr int ws_lds_bytes(int kt) { return kt * WS_BN * 128 + 8 * WS_STAGE_WAVE + WS_BN * 4; }   // W tile | transposers | bias tile
+
+// KT = K / 64 (1..4).  Grid: a multiple of nbn = N / 256 workgroups, at most one per CU; workgroup b works on column tile
+// b % nbn and takes every (gridDim / nbn)-th group of eight row groups.
+template <int KT, bool ACT, bool OUT_F32>
+__global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, void* __restrict__ out,
+                                                              int ldo, int nbn, int n_rg) {
+    constexpr int K = KT * 64, KS = KT * 2;                      // k-steps of 32
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = (blockIdx.x % nbn) * WS_BN;
+    const int slot = blockIdx.x / nbn, slots = gridDim.x / nbn;
+
+    // ---- set-up: the W tile, K-tile by K-tile: [256 cols][64 k] = 32 pieces of 8 rows x 128 B, chunk c of row r at c ^ (r&7) ----
+    {
+        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int piece = wave + p * 8;
+                glds16(W + (size_t)(n0 + piece * 8 + srow) * K + kt * 64 + schunk * 8, smem + kt * (WS_BN * 128) + piece * 1024);
+            }
+    }
+
+    // the column tile's bias: 256 floats behind the transposers.  The epilogue reads it from LDS (lgkmcnt), not from global
+    // memory: a global load there would sit behind the row group's stores in the in-order vmcnt queue, and waiting for
+    // it would wait for every store to complete.
+    float* const bias_lds = (float*)(smem + KT * (WS_BN * 128) + 8 * WS_STAGE_WAVE);
+    if (tid < WS_BN) bias_lds[tid] = bias[n0 + tid];
+
+    // ---- per-lane addresses ----
+    // W fragment (col tile j, k-step s): row (lane&15) of the tile, chunk (s&1)*4 + lane/16, swizzled; K-tile s/2
+    const int foff = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
+    const char* const wrd[2] = {smem + foff, smem + (foff ^ 64)};                          // + (s/2) * 32 KiB + j * 2 KiB
+    // activation fragment (row tile t, k-step s): row t*16 + (lane&15), k = s*32 + (lane/16)*8
+    // (addresses are a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset: two address VGPRs in all)
+    const unsigned a_lane0 = (unsigned)(((lane & 15) * K + (lane >> 4) * 8) * 2);
+    const unsigned a_lane1 = a_lane0 + 16 * K * 2;
+    // epilogue transposer (the one of k_gemm_bf16_pp, 16 rows at a time): 128-B rows, 16-B chunk c of row r at c ^ (r&7).
+    //   write side: lane holds the 8-byte unit u = jj*4 + lane/16 of row lane&15: chunk u/2, half u&1
+    //   read side:  lane reads chunk lane&7 of rows lane/8 + 8 q
+    char* const stg = smem + KT * (WS_BN * 128) + wave * WS_STAGE_WAVE;
+    const int wr = lane & 15, wq = lane >> 4;
+    const int wa = wr * 128 + (((wq >> 1) ^ (wr & 7)) << 4) + (wq & 1) * 8;                // ^ (jj * 32)
+    const int rr = lane >> 3, rc = lane & 7;
+    const int ra = rr * 128 + ((rc ^ rr) << 4);                                            // + q * 1024
+    const unsigned o_lane = (unsigned)((rr * ldo + rc * 8) * 2);                           // bf16 out: row rr, chunk rc
+    const unsigned o_lane_f32 = (unsigned)((wr * ldo + wq * 4) * 4);                       // f32 out: row wr, 4 columns at wq*4
+
+    const int rg_stride = slots * 8;
+    int rg = slot * 8 + wave;
+
+    // activation fragments: a ring of RD k-steps; the slot of k-step s is refilled with k-step s + RD of the stream
+    // (this row group's, then the next one's) as soon as its MFMAs are issued -- three k-steps (>= 1 500 cycles) ahead
+    constexpr int RD = KS == 8 ? 4 : KS;
+    bf16x8 af[RD][2];
+    auto load_a = [&](int g, int s, int slot) {
+        const char* ab = (const char*)A + (size_t)g * (WS_ROWS * K * 2) + s * 64;     // wave-uniform
+        af[slot][0] = *(const bf16x8*)(ab + a_lane0);
+        af[slot][1] = *(const bf16x8*)(ab + a_lane1);
+    };
+    if (rg < n_rg) {
+#pragma unroll
+        for (int s = 0; s < RD; ++s) load_a(rg, s, s);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's W pieces (and its first fragments) have landed
+    __syncthreads();                                             // ... and everyone else's: the only barrier of the kernel
+#ifndef WS_DIAG_NOSLEEP
+    if (wave >= 4) __builtin_amdgcn_s_sleep(KT * 8);             // start the second wave of each SIMD ~half a K loop late
+#endif
+
+    for (; rg < n_rg; rg += rg_stride) {
+        f32x4 acc[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the row group whose fragments are requested next: this wave's next one, or (at the end) the current one again --
+        // always a valid address, so the loads need no branch and hipcc can count them exactly in its vmcnt waits
+        const int next = rg + rg_stride < n_rg ? rg + rg_stride : rg;
+        // W fragments in groups of four column tiles, read one group (4 x ds_read_b128) ahead of the eight MFMAs that
+        // consume it; the scheduling barriers keep hipcc from hoisting more reads than that (it would spill)
+        constexpr int NG = KS * 4;                               // groups per row group
+        bf16x8 wf[2][4];
+        auto read_w = [&](int g, bf16x8 (&dst)[4]) {
+            const int s = g >> 2, jg = g & 3;
+            const char* wb = wrd[s & 1] + (s >> 1) * (WS_BN * 128) + jg * 4 * 2048;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = *(const bf16x8*)(wb + q * 2048);
+        };
+        read_w(0, wf[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int s = g >> 2, jg = g & 3;
+            if (g + 1 < NG) read_w(g + 1, wf[(g + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#ifdef WS_DIAG_NOMFMA                                            /* timing-only diagnostic: fragments are read, products skipped */
+                asm volatile("" :: "v"(wf[g & 1][q]), "v"(af[s % RD][0]), "v"(af[s % RD][1]));
+                continue;
+#endif
+                acc[0][jg * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][q], af[s % RD][0], acc[0][jg * 4 + q], 0, 0, 0);
+                acc[1][jg * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][q], af[s % RD][1], acc[1][jg * 4 + q], 0, 0, 0);
+            }
+            if (jg == 3) {                                       // this ring slot has fed its last MFMA
+                if (s + RD < KS) load_a(rg, s + RD, s % RD);
+                else load_a(next, s + RD - KS, s % RD);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: lane holds out[row t*16 + (lane&15)][col j*16 + 4*(lane>>4) + 0..3]; four chunks of 64 columns ----
+        const size_t row0 = (size_t)rg * WS_ROWS;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 bv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bv[jj] = *(const float4*)(bias_lds + c * 64 + jj * 16 + wq * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 v = acc[t][c * 4 + jj];
+                    float v0 = v[0] + bv[jj].x, v1 = v[1] + bv[jj].y, v2 = v[2] + bv[jj].z, v3 = v[3] + bv[jj].w;
+                    if (ACT) { silu_fast2(v0, v1); silu_fast2(v2, v3); }
+                    if (OUT_F32)
+                        *(float4*)((char*)out + ((row0 + t * 16) * ldo + n0 + c * 64 + jj * 16) * 4 + o_lane_f32) = make_float4(v0, v1, v2, v3);
+                    else
+                        *(uint2*)(stg + (wa ^ (jj * 32))) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+                if (!OUT_F32) {
+                    // same-wave LDS operations execute in issue order: the reads below see the writes above, and the next
+                    // tile's writes cannot pass these reads
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#ifdef WS_DIAG_NOSTORE                                           /* timing-only diagnostic: transposed rows are read, not stored */
+                        if (n_rg < 0)
+#endif
+                        *(uint4*)((char*)out + ((row0 + t * 16 + q * 8) * ldo + n0 + c * 64) * 2 + o_lane) = *(const uint4*)(stg + ra + q * 1024);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace dp

@@ -87,6 +87,109 @@ def test_replay_bf16(e2e, fold):
     assert np.array_equal(out[~m], x_obs[~m])
 
 
+# ---- the same at the reference's real width: hid_dim = 1024 (main.py:25), 600 epochs of the reference's M-step --------
+@pytest.fixture(scope="module")
+def e2e_wide():
+    g = load_golden("e2e_california_H1024")
+    sd = {k[4:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+    return g, sd
+
+
+def _level_sigma(g, t, k):
+    """Noise level of x_t after inner iteration k (the next level's once a level's last repeat has run)."""
+    S, R = int(g["S"]), int(g["R"])
+    lvl = min(int(k) // R, S - 1)
+    return float(t[lvl + 1]) if (int(k) % R == R - 1 or lvl == S - 1) else float(t[lvl])
+
+
+def test_replay_f32_per_step_full_width(e2e_wide):
+    """north_star: per-step outputs within 1e-3 relative in fp32, identical noise -- on a TRAINED net at H = 1024, against
+    the x_t the reference handed to each new noise level (every 20th inner iteration) and its final imputation."""
+    g, sd = e2e_wide
+    X, m, x_obs, noise = _replay_inputs(g)
+    p = _plan(sd, g, "f32")
+    out, tr = p.impute_sum(x_obs, m, 1, noise=noise, trace=True)
+    t = p.schedule()
+    out, tr = out.cpu().numpy(), tr[:, 0].cpu().numpy()
+    p.close()
+    worst = 0.0
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        lim = 1e-3 * np.maximum(np.abs(ref), max(1e-2 * _level_sigma(g, t, k), 1e-3))
+        err = np.abs(tr[int(k)] - ref)
+        worst = max(worst, float((err / lim).max()))
+        assert np.all(err <= lim), (int(k), float((err / lim).max()))
+    ref = g["replay_out"]
+    err = np.abs(out - ref)
+    assert np.all(err <= 1e-3 * np.maximum(np.abs(ref), 1e-2)), float(err.max())
+    assert np.array_equal(out[~m], x_obs[~m])
+    mae, rmse = mae_rmse(out * 2, X * 2, m)
+    assert abs(mae - g["replay_mae_rmse"][0]) <= 1e-4 * g["replay_mae_rmse"][0]
+    assert abs(rmse - g["replay_mae_rmse"][1]) <= 1e-4 * g["replay_mae_rmse"][1]
+    print(f"f32 H=1024 trained: worst per-step ratio to the 1e-3 bound {worst:.3f}, final max |d| {float(err.max()):.2e}")
+
+
+@pytest.mark.parametrize("fold", [1, 0], ids=["fold", "nofold"])
+def test_replay_bf16_full_width(e2e_wide, fold):
+    """bf16 GEMM operands (float32 accumulate, float32 sampler state) on the trained H = 1024 net, identical noise.
+    Bounds stated from measurement on MI355X (tools/bf16_trained_diag.py, 64 rows x 9 columns, 981 inner iterations):
+      per step (x_t handed to each new level)  mean |d| 3e-5 (sigma > 1) rising to 1.7e-4 (sigma < 0.1); max |d| <= 1e-3
+                                               down to sigma 0.7, then ONE sensitive chain carries 1.1e-2 to the end
+                                               -> asserted: mean <= 4e-4, max <= 2.5e-2 (at levels where |x_t| reaches 244)
+      final imputation, missing cells          max 1.10e-2, mean 5.5e-4 (fold) / 4.8e-4, 99th percentile 3.9e-3 / 4.0e-3,
+                                               0.6 % / 1.1 % of cells above SURVEY.md section 8d's 5e-3
+                                               -> asserted: 99th percentile <= 5e-3, mean <= 1e-3, max <= 2.5e-2
+      MAE / RMSE on the masked cells           -0.04 % / +0.003 % (fold), +0.04 % / +0.05 % (two GEMMs) -> asserted 1 %
+    (north_star: "looser bound stated for bf16"; the gate that matters is the 1 % on MAE / RMSE.)"""
+    from diffputer_amd import _lib
+    g, sd = e2e_wide
+    X, m, x_obs, noise = _replay_inputs(g)
+    lib = _lib.load()
+    _lib.check(lib.dp_tune(b"fold_proj", fold), "dp_tune")
+    try:
+        p = _plan(sd, g, "bf16")
+        out, tr = p.impute_sum(x_obs, m, 1, noise=noise, trace=True)
+        out, tr = out.cpu().numpy(), tr[:, 0].cpu().numpy()
+        p.close()
+    finally:
+        _lib.check(lib.dp_tune(b"fold_proj", 1), "dp_tune")
+    worst_max = worst_mean = 0.0
+    for k, ref in zip(g["trace_idx"], g["trace"]):
+        e = np.abs(tr[int(k)] - ref)
+        worst_max, worst_mean = max(worst_max, float(e.max())), max(worst_mean, float(e.mean()))
+        assert float(e.max()) <= 2.5e-2 and float(e.mean()) <= 4e-4, (int(k), float(e.max()), float(e.mean()))
+    ref = g["replay_out"]
+    e = np.abs(out - ref)[m]
+    mae, rmse = mae_rmse(out * 2, X * 2, m)
+    print(f"bf16 H=1024 trained ({'fold' if fold else 'nofold'}): per step max |d| {worst_max:.2e} mean {worst_mean:.2e}; final max "
+          f"{float(e.max()):.2e} p99 {float(np.quantile(e, 0.99)):.2e} mean {float(e.mean()):.2e}; MAE {mae:.5f} vs "
+          f"{float(g['replay_mae_rmse'][0]):.5f}, RMSE {rmse:.5f} vs {float(g['replay_mae_rmse'][1]):.5f}")
+    assert float(np.quantile(e, 0.99)) <= 5e-3 and float(e.mean()) <= 1e-3 and float(e.max()) <= 2.5e-2
+    assert abs(mae - g["replay_mae_rmse"][0]) <= 1e-2 * g["replay_mae_rmse"][0]
+    assert abs(rmse - g["replay_mae_rmse"][1]) <= 1e-2 * g["replay_mae_rmse"][1]
+    assert np.array_equal(out[~m], x_obs[~m])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_free_run_metrics_full_width(e2e_wide, dtype):
+    """Production mode (Philox noise) on all 2 044 held-out rows, 5 trials, against the reference's two free runs (torch's
+    generator, two seeds) at H = 1024.  MAE and RMSE on the masked cells are statistics of 5 518 cells x 5 trials; the two
+    reference seeds bracket their sampling noise.  Gate: within 1 % of the reference's two-seed mean, plus the distance
+    between the reference's own two seeds."""
+    from diffputer_amd import estep
+    g, sd = e2e_wide
+    X, m, T = g["X_test"], g["mask_test"], int(g["free_trials"])
+    p = _plan(sd, g, dtype)
+    rec = estep.impute_trials(p, np.asfortranarray(X), m, T, seed=2025).cpu().numpy()
+    p.close()
+    ours = np.asarray(mae_rmse(rec * 2, X * 2, m))
+    ref = np.asarray(g["free_mae_rmse"])
+    mid, spread = ref.mean(0), np.abs(ref[0] - ref[1])
+    print(f"free run H=1024 {dtype}: MAE/RMSE {ours} vs reference seeds {ref.tolist()}")
+    assert np.all(np.abs(ours - mid) <= 1e-2 * mid + spread), (ours, ref)
+    zf = g["zero_fill_mae_rmse"]
+    assert ours[0] < 0.8 * zf[0] and ours[1] < 0.9 * zf[1], "a trained denoiser must clearly beat zero-fill"
+
+
 def _robust(rec, X, m, clip=3.0):
     """MAE, RMSE of the masked-cell errors clipped at `clip` (6 sigma_data in the x2 scale), and their median."""
     err = np.minimum(np.abs((rec - X) * 2)[m], clip)

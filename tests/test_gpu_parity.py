@@ -71,9 +71,12 @@ def test_linear_bf16(M, N, K, act):
         assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max()
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 2048, 256), (256 * 33, 2048, 192), (256 * 70, 1024, 512), (256 * 3, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 256), (256 * 33, 2048, 192), (256 * 70, 1024, 512), (256 * 3, 256, 1024),
+                                   (256 * 35, 2048, 64), (256, 256, 128), (256 * 9, 512, 256), (256 * 131, 1024, 64)])
 def test_linear_bf16_persistent(M, N, K):
-    """The ping-pong kernel beyond one tile per workgroup: whole rounds, a ragged last round, fewer tiles than CUs.
+    """The persistent kernels beyond one tile per workgroup: whole rounds, a ragged last round, fewer tiles than CUs --
+    the ping-pong kernel (K >= 192... with K > 256) and the weight-stationary kernel (K <= 256: every K-tile count, more
+    and fewer row groups than waves, 1 to 8 column tiles).
     Checker: torch fp32 matmul of the same bf16 operands on the device; and the simple kernel, bit for bit."""
     from diffputer_amd import _lib
     from diffputer_amd.sampler import linear

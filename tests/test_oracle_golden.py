@@ -159,6 +159,27 @@ def test_trained_checkpoint_replay():
     assert abs(mae - g["replay_mae_rmse"][0]) < 1e-5 and abs(rmse - g["replay_mae_rmse"][1]) < 1e-5
 
 
+def test_trained_checkpoint_replay_full_width():
+    """The same at the reference's real width: tests/golden/e2e_california_H1024.npz (hid_dim = 1024, main.py:25; 600 epochs
+    of the reference's M-step).  The oracle runs the first 12 of the 64 replay rows (rows are independent chains, so a row
+    subset with the matching slice of the noise stream reproduces those rows) and is held to the reference's final output
+    and to its per-iteration x_t (every 20th inner iteration = the state handed to each new noise level)."""
+    g = load_golden("e2e_california_H1024")
+    sd = {k[4:].replace("__", "."): v for k, v in g.items() if k.startswith("sd__")}
+    n, d, S, R, k = int(g["replay_rows"]), int(g["d_in"]), int(g["S"]), int(g["R"]), 12
+    noise = synth.reference_noise(int(g["nseed"]), synth.n_draws(S, R), (n, d))
+    assert float(np.asarray(noise, dtype=np.float64).sum()) == float(g["noise_checksum"])
+    X, m = g["X_test"][:k], g["mask_test"][:k]
+    x_obs = (X * (1.0 - m)).astype(np.float32)
+    trace = []
+    out = orc.impute_mask(sd, x_obs, m, np.ascontiguousarray(noise[:, :k]), S, R, trace)
+    close(out * m + x_obs * (1.0 - m), g["replay_out"][:k], atol=2e-5, rtol=1e-4)
+    t = orc.sigma_schedule(S)
+    for idx, ref in zip(g["trace_idx"], g["trace"]):
+        lvl = min(int(idx) // R, S - 1)
+        close(trace[int(idx)], ref[:k], atol=2e-5 * max(1.0, float(t[lvl + 1])), rtol=1e-4)
+
+
 def test_variants_sample_and_missdiff():
     """`sample` and the MissDiff baseline's impute_mask (N = 10, no final level), both run from the reference."""
     g = load_golden("sample_D9_H64_S10")

@@ -22,6 +22,7 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--only", default=None)
 ap.add_argument("--act", type=int, default=1)
+ap.add_argument("--ab", default=None, help="toggle a dp_tune key instead of gemm_variant: key:v0,v1 (e.g. ws_gemm:0,1)")
 ap.add_argument("--shapes", default=None, help="extra shapes as N:K,N:K (replaces the default list)")
 a = ap.parse_args()
 if os.environ.get('DP_DIAG_LIB'):
@@ -29,6 +30,10 @@ if os.environ.get('DP_DIAG_LIB'):
 lib = _lib.load()
 dev = "cuda:0"
 variants = [int(v) for v in a.variants.split(",")]
+ab_key = b"gemm_variant"
+if a.ab:
+    k, vs = a.ab.split(":")
+    ab_key, variants = k.encode(), [int(v) for v in vs.split(",")]
 shapes = [("mlp.0", 2048, 1024), ("mlp.2", 2048, 2048), ("mlp.4", 1024, 2048), ("proj256", 1024, 256), ("mlp.6/256", 256, 1024)]
 if a.shapes:
     shapes = [(f"N{n}K{k}", int(n), int(k)) for n, k in (x.split(":") for x in a.shapes.split(","))]
@@ -43,7 +48,7 @@ for name, N, K in shapes:
     outs = {}
     for r in range(a.rounds):
         for v in variants:
-            _lib.check(lib.dp_tune(b"gemm_variant", v), "dp_tune")
+            _lib.check(lib.dp_tune(ab_key, v), "dp_tune")
             o = linear(A, W, b, act=bool(a.act))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
