@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
+    ap.add_argument("--tune", action="append", default=[], help="dp_tune key=value (A/B runs), e.g. --tune ws_gemm=0")
     ap.add_argument("--m-chunk", type=int, default=None, help="rows per wide-layer GEMM launch (dp_tune m_chunk; 0 = whole batch)")
     a = ap.parse_args()
     preset = CONFIGS[a.config]
@@ -203,6 +204,9 @@ def main():
         _lib.check(_lib.load().dp_tune(b"fold_proj", 0 if a.no_fold else 1), "dp_tune")
         if a.m_chunk is not None:
             _lib.check(_lib.load().dp_tune(b"m_chunk", a.m_chunk), "dp_tune")
+        for kv in a.tune:
+            k, v = kv.split("=")
+            _lib.check(_lib.load().dp_tune(k.encode(), int(v)), "dp_tune")
         # random-init weights of the reference architecture (throughput is weight-independent), synthetic table shard
         sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(d, hid, seed=1, gain=1.0).items()}
         plan = SamplerPlan(sd, num_steps=S, n_resample=R, dtype=a.dtype, device=dev)

@@ -88,7 +88,8 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
 static std::atomic<int> g_gemm_variant{2};
 static std::atomic<int> g_fold_proj{1};
 static std::atomic<int> g_m_chunk{32768};  // "m_chunk": rows per launch of the wide layers in bf16 plans (0 = whole batch), see eval_F
-static std::atomic<int> g_ws_gemm{1};      // "ws_gemm": 1 = weight-stationary kernel for layers with K <= 256 and N % 256 == 0 (bf16 plans)
+static std::atomic<int> g_ws_gemm{1};      // "ws_gemm": weight-stationary kernel for shallow layers with N % 256 == 0 (bf16 plans):
+                                           // 1 = where it wins, K <= 128 (default); 2 = wherever it runs, K <= 256; 0 = never
 static std::atomic<int> g_fuse_mid{1};     // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 static inline int tune(const std::atomic<int>& v) { return v.load(std::memory_order_relaxed); }
 
@@ -235,7 +236,8 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
     if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
-        if (N % 256 == 0 && K <= 256 && tune(g_ws_gemm) && tune(g_gemm_variant) == 2)
+        const int ws = tune(g_ws_gemm);
+        if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && tune(g_gemm_variant) == 2)
             return launch_bf16_ws((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) == 2)
             return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
@@ -820,7 +822,7 @@ int dp_tune(const char* key, int value) {
         return DP_OK;
     }
     if (!strcmp(key, "ws_gemm")) {
-        if (value < 0 || value > 1) return fail(DP_EINVAL, "ws_gemm must be 0 or 1");
+        if (value < 0 || value > 2) return fail(DP_EINVAL, "ws_gemm must be 0, 1 or 2");
         g_ws_gemm = value;
         return DP_OK;
     }

@@ -23,9 +23,23 @@
 
 namespace dp {
 
+// Diagnostic build only (-DDP_PP_STAMP -DWS_STAMP, tools/ws_stamps.py): s_memtime stamps per wave and row group into the
+// debug buffer of dp_gemm_bf16_pp.h ([block][wave][16][4] u64); no stamp executes in the shipped library.
+#ifdef WS_STAMP
+extern __device__ unsigned long long* g_pp_stamp_buf;
+#define WS_STAMP_AT(var)                                                                                        \
+    do {                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+#else
+#define WS_STAMP_AT(var) do { } while (0)
+#endif
+
 constexpr int WS_BN = 256, WS_ROWS = 32, WS_THREADS = 512;
 constexpr int WS_STAGE_WAVE = 2048;                              // epilogue transposer per wave (16 rows x 128 B)
-constexpr int ws_lds_bytes(int kt) { return kt * WS_BN * 128 + 8 * WS_STAGE_WAVE + WS_BN * 4; }   // W tile | transposers | bias tile
+constexpr int ws_lds_bytes(int kt) { return kt * WS_BN * 128 + 8 * WS_STAGE_WAVE + WS_BN * 4 + 16; }   // W tile | transposers | bias tile | ticket
 
 // KT = K / 64 (1..4).  Grid: a multiple of nbn = N / 256 workgroups, at most one per CU; workgroup b works on column tile
 // b % nbn and takes every (gridDim / nbn)-th group of eight row groups.
@@ -37,6 +51,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WS_STAMP
+    unsigned long long st_k0 = 0, st_a = 0, st_b = 0, st_c = 0;
+    int st_i = 0;
+    WS_STAMP_AT(st_k0);
+#endif
     const int n0 = (blockIdx.x % nbn) * WS_BN;
     const int slot = blockIdx.x / nbn, slots = gridDim.x / nbn;
 
@@ -57,6 +76,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
     // it would wait for every store to complete.
     float* const bias_lds = (float*)(smem + KT * (WS_BN * 128) + 8 * WS_STAGE_WAVE);
     if (tid < WS_BN) bias_lds[tid] = bias[n0 + tid];
+    // row groups are handed out by a ticket counter in LDS: on each SIMD the older wave wins the issue arbitration and
+    // gets through its row groups faster, so a static split leaves the younger waves a tail with nobody to overlap with
+    int* const ticket = (int*)(bias_lds + WS_BN);
+    if (tid == 0) *ticket = 8;                                   // tickets 0..7 are the waves' first row groups
 
     // ---- per-lane addresses ----
     // W fragment (col tile j, k-step s): row (lane&15) of the tile, chunk (s&1)*4 + lane/16, swizzled; K-tile s/2
@@ -77,8 +100,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
     const unsigned o_lane = (unsigned)((rr * ldo + rc * 8) * 2);                           // bf16 out: row rr, chunk rc
     const unsigned o_lane_f32 = (unsigned)((wr * ldo + wq * 4) * 4);                       // f32 out: row wr, 4 columns at wq*4
 
-    const int rg_stride = slots * 8;
-    int rg = slot * 8 + wave;
+    // this workgroup's row groups: slot + i * slots, i = 0, 1, ...  (ticket i -> row group)
+    const int n_mine = n_rg > slot ? (n_rg - slot + slots - 1) / slots : 0;
+    auto rg_of = [&](int i) { return slot + i * slots; };
+    int ti = wave;                                               // my current ticket
+    int rg = rg_of(ti);
 
     // activation fragments: a ring of RD k-steps; the slot of k-step s is refilled with k-step s + RD of the stream
     // (this row group's, then the next one's) as soon as its MFMAs are issued -- three k-steps (>= 1 500 cycles) ahead
@@ -89,7 +115,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
         af[slot][0] = *(const bf16x8*)(ab + a_lane0);
         af[slot][1] = *(const bf16x8*)(ab + a_lane1);
     };
-    if (rg < n_rg) {
+    if (ti < n_mine) {
 #pragma unroll
         for (int s = 0; s < RD; ++s) load_a(rg, s, s);
     }
@@ -100,7 +126,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
     if (wave >= 4) __builtin_amdgcn_s_sleep(KT * 8);             // start the second wave of each SIMD ~half a K loop late
 #endif
 
-    for (; rg < n_rg; rg += rg_stride) {
+    while (ti < n_mine) {
+        // next ticket (wave-uniform: one lane draws it)
+        int tn = 0;
+        if (lane == 0) tn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tn = __builtin_amdgcn_readfirstlane(tn);
+        WS_STAMP_AT(st_a);
         f32x4 acc[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -108,7 +139,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
             for (int j = 0; j < 16; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // the row group whose fragments are requested next: this wave's next one, or (at the end) the current one again --
         // always a valid address, so the loads need no branch and hipcc can count them exactly in its vmcnt waits
-        const int next = rg + rg_stride < n_rg ? rg + rg_stride : rg;
+        const int next = tn < n_mine ? rg_of(tn) : rg;
         // W fragments in groups of four column tiles, read one group (4 x ds_read_b128) ahead of the eight MFMAs that
         // consume it; the scheduling barriers keep hipcc from hoisting more reads than that (it would spill)
         constexpr int NG = KS * 4;                               // groups per row group
@@ -140,6 +171,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        WS_STAMP_AT(st_b);
         // ---- epilogue: lane holds out[row t*16 + (lane&15)][col j*16 + 4*(lane>>4) + 0..3]; four chunks of 64 columns ----
         const size_t row0 = (size_t)rg * WS_ROWS;
 #pragma unroll
@@ -171,6 +203,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
                 }
             }
         }
+#ifdef WS_STAMP
+        WS_STAMP_AT(st_c);
+        if (g_pp_stamp_buf && st_i < 16 && lane == 0) {
+            unsigned long long* d = g_pp_stamp_buf + (((size_t)blockIdx.x * 8 + wave) * 16 + st_i) * 4;
+            d[0] = st_k0; d[1] = st_a; d[2] = st_b; d[3] = st_c;
+        }
+        ++st_i;
+#endif
+        ti = tn;
+        rg = next;
     }
 }
 

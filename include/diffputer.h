@@ -191,6 +191,11 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
  *   "m_chunk"       rows per launch of the wide layers in bf16 plans (default 32768; 0 = the whole batch in one launch):
  *                   proj+mlp.0, mlp.2, mlp.4 run chunk after chunk so that a chunk's activations stay in the Infinity
  *                   Cache between layers; rows are independent, results do not change.
+ *   "ws_gemm"       which layers run on the weight-stationary kernel (dp_gemm_bf16_ws.h: the W tile stays in LDS, every wave
+ *                   streams its own rows, no barrier after set-up, one wave's SiLU epilogue under its SIMD partner's MFMAs):
+ *                   1 (default) = layers with K <= 128 (the folded proj+mlp.0 layer of tables up to 128 columns: 55 -> 31 us
+ *                   per 32 768 x 2048 launch at K = 64), 2 = K <= 256 as well (on par with the ping-pong kernel there),
+ *                   0 = never.  Bit-identical results.
  *   "fuse_mid"      1 (default) = for bf16 plans with d_in = 256 the arithmetic after a Heun iteration's first evaluation
  *                   (diffusion_utils.py:100-101) runs in the epilogue of the mlp.6 GEMM instead of a kernel of its own;
  *                   bit-identical results.

@@ -87,11 +87,19 @@ def test_linear_bf16_persistent(M, N, K):
     ref = torch.nn.functional.silu(A.float() @ W.float().T + b)
     lib = _lib.load()
     outs = {}
-    for variant in (2, 1):
-        _lib.check(lib.dp_tune(b"gemm_variant", variant), "dp_tune")
-        outs[variant] = linear(A, W, b, act=True)
-        outs[(variant, "f32")] = linear(A, W, b, act=True, out_f32=True)
-    _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+    _lib.check(lib.dp_tune(b"ws_gemm", 2), "dp_tune")                  # K <= 256 -> weight-stationary kernel, else ping-pong
+    try:
+        for variant in (2, 1):
+            _lib.check(lib.dp_tune(b"gemm_variant", variant), "dp_tune")
+            outs[variant] = linear(A, W, b, act=True)
+            outs[(variant, "f32")] = linear(A, W, b, act=True, out_f32=True)
+        _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+        if 192 <= K <= 256:                                          # both persistent kernels take these shapes
+            _lib.check(lib.dp_tune(b"ws_gemm", 0), "dp_tune")
+            assert torch.equal(linear(A, W, b, act=True), outs[2])
+    finally:
+        _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+        _lib.check(lib.dp_tune(b"ws_gemm", 1), "dp_tune")
     assert torch.equal(outs[2], outs[1]) and torch.equal(outs[(2, "f32")], outs[(1, "f32")])
     assert torch.allclose(outs[2].float(), ref, rtol=1e-2, atol=1e-2), (outs[2].float() - ref).abs().max()
     assert torch.allclose(outs[(2, "f32")], ref, rtol=2e-3, atol=2e-3), (outs[(2, "f32")] - ref).abs().max()

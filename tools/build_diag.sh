@@ -5,3 +5,5 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/diag
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -DDP_PP_STAMP \
     -o tools/diag/libdiffputer_hip_stamp.so diffputer_amd/csrc/diffputer_hip.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -DDP_PP_STAMP -DWS_STAMP \
+    -o tools/diag/libdp_ws_stamp.so diffputer_amd/csrc/diffputer_hip.hip
