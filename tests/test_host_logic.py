@@ -347,8 +347,11 @@ def test_committed_bench_line_keeps_the_contract():
     assert paths, "no bench line under profiles/"
     r = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "ranks", "backend", "whole_path"):
         assert k in r, k
+    assert r["ranks"] == r["n_gpus"]
+    wp = r["whole_path"]                                   # executed FLOPs first; the reference's 5-layer model second
+    assert wp["frac_of_mfma_peak"] <= wp["model_equivalent_frac_of_mfma_peak"] and "executed_flops_per_row" in wp
     assert r["unit"] == "rows/s" and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
     assert r["dtype"] == "bf16" and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
     rf = r["roofline"]
