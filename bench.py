@@ -312,7 +312,18 @@ def main():
             avg_flops = sum(layer_flops[i] for i in (1, 2, 3)) / 3.0
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mc)
-            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+            clock = {}
+            if a.dtype == "bf16":
+                cyc, us, n = plan.profile_clock()
+                if n:
+                    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+                    fpc = layer_flops[2] / (cyc / n) / cus                # mlp.2 launch FLOPs per shader cycle per CU
+                    clock = {"clock_mhz_in_kernel": cyc / us, "clock_samples": n, "mlp2_kernel_cycles": cyc / n,
+                             "mlp2_flop_per_cycle_per_cu": fpc, "mfma_peak_flop_per_cycle_per_cu": 4096,
+                             "mlp2_frac_of_mfma_peak_at_clock_held": fpc / 4096.0,
+                             "clock_note": "s_memtime / s_memrealtime of workgroup 0 of the sampled mlp.2 launches; 4096 = 4 SIMDs x "
+                                           "1024 FLOP per cycle (v_mfma_f32_16x16x32_bf16: 16 384 FLOP per 16 cycles); the 2.5 PFLOP/s peak assumes 2.4 GHz"}
+            result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **clock,
                                   "traffic_source": traffic_src,
                                   "kernel": ("k_gemm_bf16_pp<SiLU,bf16-out> (" + ("proj+mlp.0" if folded else "mlp.0") + ", mlp.2, mlp.4)") if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
                                   "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mc}

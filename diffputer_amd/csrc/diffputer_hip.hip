@@ -69,6 +69,7 @@ struct dp_plan {
     int prof_used = 0;                   // samples recorded
     std::vector<hipEvent_t> prof_ev;     // DP_PROF_SAMPLES * 7 events: before GEMM-1, after GEMM-1..5, after the step kernel
     std::vector<int> prof_tag;           // which step kernel followed: 0 mid, 1 end, 2 final
+    unsigned long long* prof_clk = nullptr;   // device [DP_PROF_SAMPLES][4]: in-kernel clock sample of the mlp.2 launch of each profiled evaluation
     void* static_ws = nullptr;           // this device's copy of the file-scope scratch array (dp_impute_static), resolved at create
     size_t esize() const { return dtype == DP_DTYPE_BF16 ? 2 : 4; }
 };
@@ -118,7 +119,7 @@ static const DeviceState* device_state() {
 }
 
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
-                          int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr) {
+                          int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr, unsigned long long* clk = nullptr) {
     const int nbn = N / PP_BN;
     const int64_t nwg64 = (M / PP_BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
@@ -126,7 +127,8 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     const DeviceState* ds = device_state();
     if (!ds) return DP_EHIP;
     const int num_cus = ds->num_cus;
-    const MidStep ms = mid ? *mid : MidStep{};
+    MidStep ms = mid ? *mid : MidStep{};
+    ms.clk = clk;
 #define DP_GO(ACT, EP)                                                                                              \
     hipLaunchKernelGGL((k_gemm_bf16_pp<ACT, EP>), dim3(std::min(nwg, num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms)
     if (mid) {
@@ -232,7 +234,7 @@ static int ensure_device_ready(int dev) {
 }
 
 static int gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int ldo, int64_t M, int N, int K, int act,
-                int out_f32, hipStream_t st) {
+                int out_f32, hipStream_t st, unsigned long long* clk = nullptr) {
     if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
@@ -240,7 +242,7 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
         if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && tune(g_gemm_variant) == 2)
             return launch_bf16_ws((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) == 2)
-            return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
+            return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
         if (N % 256 == 0)
             return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         return launch_bf16_cfg<256, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
@@ -334,7 +336,9 @@ static int eval_F(const dp_plan* p, const Workspace& w, int level, hipStream_t s
             if ((rc = gemm(dt, a1, p->W[1], p->B[1], b2, 2 * H, m, 2 * H, H, 1, 0, st))) return rc;  // mlp.0 + SiLU
         }
         DP_EV(2);
-        if ((rc = gemm(dt, b2, p->W[2], p->B[2], a2, 2 * H, m, 2 * H, 2 * H, 1, 0, st))) return rc;  // mlp.2 + SiLU
+        // profiled evaluation: the mlp.2 launch of the last chunk also samples the clock the chip holds under it
+        unsigned long long* clk = ev && last && p->prof_clk ? p->prof_clk + 4 * ((ev - p->prof_ev.data()) / 7) : nullptr;
+        if ((rc = gemm(dt, b2, p->W[2], p->B[2], a2, 2 * H, m, 2 * H, 2 * H, 1, 0, st, clk))) return rc;  // mlp.2 + SiLU
         DP_EV(3);
         if ((rc = gemm(dt, a2, p->W[3], p->B[3], b1, H, m, H, 2 * H, 1, 0, st))) return rc;          // mlp.4 + SiLU
         DP_EV(4);
@@ -404,6 +408,8 @@ static int check_plan(const dp_plan* p, bool need_weights) {
 static void free_plan_events(dp_plan* p) {
     for (auto e : p->prof_ev) (void)hipEventDestroy(e);
     p->prof_ev.clear();
+    if (p->prof_clk) (void)hipFree(p->prof_clk);
+    p->prof_clk = nullptr;
     p->prof_stride = 0;
 }
 
@@ -672,7 +678,9 @@ int dp_plan_profile(dp_plan* p, int stride) {
         p->prof_ev.resize((size_t)7 * DP_PROF_SAMPLES);
         p->prof_tag.assign(DP_PROF_SAMPLES, 0);
         for (auto& e : p->prof_ev) DP_HIP(hipEventCreate(&e));
+        DP_HIP(hipMalloc((void**)&p->prof_clk, (size_t)DP_PROF_SAMPLES * 4 * sizeof(unsigned long long)));
     }
+    if (stride) DP_HIP(hipMemset(p->prof_clk, 0, (size_t)DP_PROF_SAMPLES * 4 * sizeof(unsigned long long)));
     p->prof_stride = stride;
     p->prof_evals = 0;
     p->prof_used = 0;
@@ -695,6 +703,26 @@ int dp_plan_profile_read(dp_plan* p, double ms_sum[8], int count[8]) {
             ms_sum[slot] += ms;
             count[slot] += 1;
         }
+    }
+    return DP_OK;
+}
+
+int dp_plan_profile_clock(dp_plan* p, double* cycles_sum, double* wall_us_sum, int* count) {
+    int rc = check_plan(p, false);
+    if (rc) return rc;
+    if (!cycles_sum || !wall_us_sum || !count) return fail(DP_EINVAL, "NULL argument");
+    *cycles_sum = *wall_us_sum = 0.0;
+    *count = 0;
+    if (!p->prof_clk || !p->prof_used) return DP_OK;
+    for (int s = 0; s < p->prof_used; ++s) DP_HIP(hipEventSynchronize(p->prof_ev[(size_t)7 * s + 6]));
+    std::vector<unsigned long long> h((size_t)p->prof_used * 4);
+    DP_HIP(hipMemcpy(h.data(), p->prof_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int s = 0; s < p->prof_used; ++s) {
+        const unsigned long long c0 = h[4 * s], c1 = h[4 * s + 1], r0 = h[4 * s + 2], r1 = h[4 * s + 3];
+        if (c1 <= c0 || r1 <= r0) continue;                        // no ping-pong mlp.2 launch in this sample (narrow plan, f32)
+        *cycles_sum += (double)(c1 - c0);
+        *wall_us_sum += (double)(r1 - r0) * 0.01;                   // s_memrealtime ticks at 100 MHz
+        *count += 1;
     }
     return DP_OK;
 }

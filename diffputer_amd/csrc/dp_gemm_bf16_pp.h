@@ -84,6 +84,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int G = gridDim.x;
+    // in-situ clock sample (one pair of scalar reads per LAUNCH, only when the host asked for it): workgroup 0's lifetime
+    // (written out at once: nothing of it stays live across the K loops)
+    if (ms.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        ms.clk[0] = __builtin_amdgcn_s_memtime();
+        ms.clk[2] = __builtin_amdgcn_s_memrealtime();
+    }
     const int nk = K / PP_BK;                                   // host guarantees nk >= 3
 
     // ---- staging: a wave moves pieces `wave` and `wave + 8` of every half-tile (a piece = 8 rows x 128 B) ----
@@ -423,6 +429,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
 #endif
         if (!more) break;
         first = !PREFETCH;                                       // without the prefetch no stores sit behind the prologue DMA
+    }
+
+    if (ms.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        ms.clk[1] = __builtin_amdgcn_s_memtime();
+        ms.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
 
 #undef PP_WAIT_MAIN

@@ -43,6 +43,9 @@ struct MidStep {
     int64_t m_valid;       // chains; GEMM rows beyond it are padding
     int ldu;
     float c_skip, c_out, t_hat, h, c_in_next;
+    unsigned long long* clk;   // NULL, or 4 words that workgroup 0 of the launch fills: shader-clock ticks (s_memtime) at its
+                               // start and end, 100 MHz wall ticks (s_memrealtime) at its start and end -> the clock the
+                               // chip held under this kernel (bench.py's in-situ profiling samples only)
 };
 
 struct Cell { int64_t m, row; int col, tl; };

@@ -133,6 +133,13 @@ class SamplerPlan:
             _lib.check(self.lib.dp_plan_profile_read(self._h, ms, cnt), "dp_plan_profile_read")
         return list(ms), list(cnt)
 
+    def profile_clock(self):
+        """(shader cycles, wall microseconds, samples) summed over the profiled mlp.2 launches: the in-kernel clock."""
+        cyc, us, n = C.c_double(), C.c_double(), C.c_int()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dp_plan_profile_clock(self._h, C.byref(cyc), C.byref(us), C.byref(n)), "dp_plan_profile_clock")
+        return cyc.value, us.value, n.value
+
     def gemm_rows(self, n_chains: int) -> int:
         """Rows per launch of the wide-layer GEMMs for a call of `n_chains` chains (dp_tune "m_chunk")."""
         return int(self.lib.dp_plan_gemm_rows(self._h, int(n_chains)))

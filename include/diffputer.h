@@ -171,6 +171,12 @@ int dp_plan_profile(dp_plan* plan, int stride);
  * With chunking on, profile slots 0..3 time the launches of ONE chunk.  0 on error. */
 int64_t dp_plan_gemm_rows(const dp_plan* plan, int64_t n_chains);
 int dp_plan_profile_read(dp_plan* plan, double ms_sum[8], int count[8]);
+/* The clock the chip held under the dominant kernel: every profiled evaluation's mlp.2 launch (ping-pong kernel) has its
+ * workgroup 0 read the shader clock (s_memtime) and the 100 MHz wall clock (s_memrealtime) at its start and end -- two
+ * scalar reads per LAUNCH, none in unprofiled launches.  Returns the sums over the samples: shader cycles and wall
+ * microseconds of that workgroup's lifetime (clock = cycles / us MHz; FLOP per cycle = launch FLOPs / cycles).  No
+ * counterpart in the reference. */
+int dp_plan_profile_clock(dp_plan* plan, double* cycles_sum, double* wall_us_sum, int* count);
 
 /*
  * Single-kernel test entry: out[M, N] = act(A[M, K] @ W[N, K]^T + bias[N]) with the plan-independent GEMM

@@ -27,6 +27,10 @@ ap.add_argument("--shapes", default=None, help="extra shapes as N:K,N:K (replace
 a = ap.parse_args()
 if os.environ.get('DP_DIAG_LIB'):
     _lib.LIB_PATH = os.environ['DP_DIAG_LIB']                # A/B a diagnostic build on one box
+    import ctypes
+    _probe = ctypes.CDLL(_lib.LIB_PATH)                      # an older build may lack the newest entry points
+    for _name in [n for n in _lib.SIGNATURES if not hasattr(_probe, n)]:
+        del _lib.SIGNATURES[_name]
 lib = _lib.load()
 dev = "cuda:0"
 variants = [int(v) for v in a.variants.split(",")]
