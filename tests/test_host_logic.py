@@ -322,6 +322,17 @@ def test_mstep_loss_and_gradient_match_reference():
     check_mstep(load_golden("mstep_D12_H64"), "cpu", 1e-5)
 
 
+def test_pingpong_gemm_counted_waits_match_the_emitted_code():
+    """tools/check_pp_asm.py: the vmcnt(8 + NST) / vmcnt(10 + NST) waits of k_gemm_bf16_pp assume NST epilogue stores sit
+    behind the next tile's prologue DMA; compile the kernel and count them in the gfx950 assembly (also: no scratch)."""
+    import subprocess
+    import sys
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_pp_asm.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_prep_helpers_match_reference():
     """evalmetrics.mean_std / mae_rmse against the reference's mean_std (dataset.py:161-169) and get_eval (:171-206)
     run on 2 048 california rows (tools/make_prep_golden.py)."""
