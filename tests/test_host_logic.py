@@ -333,6 +333,49 @@ def test_pingpong_gemm_counted_waits_match_the_emitted_code():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_dataset_module_reads_files_like_the_reference(tmp_path):
+    """diffputer_amd.dataset.load_dataset / get_eval with the reference's signatures, on CSV / JSON / .npy files written from
+    the columns tests/golden/layout_mixed.npz stores (the same table the reference's load_dataset read when the fixture
+    was made): the 11-tuple must equal the reference's arrays; the numeric-only branch is exercised on a second table."""
+    import json
+    import pandas as pd
+    from conftest import load_golden
+    from diffputer_amd import dataset as ds
+    g = load_golden("layout_mixed")
+    ni, ci = [int(j) for j in g["num_col_idx"]], [int(j) for j in g["cat_col_idx"]]
+    ncol = max(ni + ci) + 2                                            # + the target column
+    names = [f"c{j}" for j in range(ncol)]
+    root = tmp_path / "datasets"
+    (root / "mixed" / "masks" / "rate30" / "MCAR").mkdir(parents=True)
+    (root / "Info").mkdir()
+    for tag in ("data", "train", "test"):
+        n = len(g[f"{tag}_num_{ni[0]}"])
+        df = {names[j]: g[f"{tag}_num_{j}"] for j in ni} | {names[j]: g[f"{tag}_cat_{j}"] for j in ci}
+        df[names[ncol - 1]] = np.zeros(n)
+        pd.DataFrame({c: df[c] for c in names if c in df}, columns=names).to_csv(root / "mixed" / f"{tag}.csv", index=False)
+    json.dump({"name": "mixed", "num_col_idx": ni, "cat_col_idx": ci, "target_col_idx": [ncol - 1]}, open(root / "Info" / "mixed.json", "w"))
+    np.save(root / "mixed" / "masks" / "rate30" / "MCAR" / "train_mask_0.npy", g["train_mask0"])
+    np.save(root / "mixed" / "masks" / "rate30" / "MCAR" / "test_mask_0.npy", g["test_mask0"])
+    out = ds.load_dataset("mixed", 0, "MCAR", "30", data_dir=str(root))
+    want = [g[k] for k in ("train_X", "test_X", "train_mask0", "test_mask0", "train_num", "test_num", "train_cat_idx", "test_cat_idx",
+                           "train_mask", "test_mask", "cat_bin_num")]
+    assert len(out) == 11
+    for got, ref in zip(out, want):
+        assert np.array_equal(got, ref) and got.dtype == ref.dtype
+    mean, std = ds.mean_std(out[0], out[8])
+    assert np.allclose(mean, g["mean"], rtol=1e-6, atol=0) and np.allclose(std, g["std"], rtol=1e-6, atol=1e-12)
+    # get_eval: the mask over the ORIGINAL columns is sliced by num_col_idx; a zero prediction scores the numeric truth itself
+    Xn = np.where(std > 0, (out[0] - mean) / np.where(std > 0, std, 1), 0).astype(np.float32)
+    mae, rmse = ds.get_eval("mixed", np.zeros_like(Xn), Xn, out[6], len(ni), out[10], out[2], data_dir=str(root))
+    nm = g["train_mask0"][:, ni]
+    assert abs(mae - float(np.abs(Xn[:, :len(ni)][nm]).mean())) < 1e-6
+    # numeric-only table: categorical entries are None, the extended mask is the numeric slice (dataset.py:61-66)
+    json.dump({"name": "mixed", "num_col_idx": ni, "cat_col_idx": [], "target_col_idx": [ncol - 1]}, open(root / "Info" / "mixed.json", "w"))
+    o2 = ds.load_dataset("mixed", 0, "MCAR", "30", data_dir=str(root))
+    assert o2[6] is None and o2[7] is None and o2[10] is None
+    assert np.array_equal(o2[0], g["train_num"]) and np.array_equal(o2[8], g["train_mask0"][:, ni])
+
+
 def test_prep_helpers_match_reference():
     """evalmetrics.mean_std / mae_rmse against the reference's mean_std (dataset.py:161-169) and get_eval (:171-206)
     run on 2 048 california rows (tools/make_prep_golden.py)."""
