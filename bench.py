@@ -276,7 +276,8 @@ def main():
                                f"hid={hid}; each step = full E-step of a {a.rows}-row shard per GPU (MCAR 30%, random-init weights)",
                    "name": a.config,
                    "rows_per_step_per_gpu": a.rows, "cols": d, "num_steps": S, "n_resample": R, "num_trials": T, "hid": hid,
-                   "chains_per_call": min(a.max_chains, a.rows * T), "wide_gemm_rows_per_launch": plan.gemm_rows(min(a.max_chains, a.rows * T)),
+                   "chains_per_call": max((r1 - r0) * (t1 - t0) for r0, r1, t0, t1 in estep.plan_calls(a.rows, T, a.max_chains)),
+                   "wide_gemm_rows_per_launch": plan.gemm_rows(max((r1 - r0) * (t1 - t0) for r0, r1, t0, t1 in estep.plan_calls(a.rows, T, a.max_chains))),
                    "parallelism": f"row-shard x{world}, all-gather of trial means"},
         "row_trials_per_s": rows_per_s * T, "denoiser_row_evals_per_s": rows_per_s * T * nfe,
         # primary figures = FLOPs the GEMM kernels execute; the reference's FLOP model (5 layers, 4DH + 16H^2 per
@@ -292,9 +293,12 @@ def main():
 
     if rank == 0 and not a.no_profile:
         ms, cnt = plan.profile_read()
-        chains = min(a.max_chains, a.rows * T)
-        Mp = -(-chains // 256) * 256
-        Mc = plan.gemm_rows(chains)                    # rows per launch of the wide layers (the batch runs in chunks)
+        # rows per profiled launch: the calls of one step may differ in size (plan_calls), every call runs the same number of
+        # evaluations and the samples are spread evenly over them, so time and FLOPs are both averaged over the calls
+        call_chains = [(r1 - r0) * (t1 - t0) for r0, r1, t0, t1 in estep.plan_calls(a.rows, T, a.max_chains)]
+        chains = sum(call_chains) / len(call_chains)
+        Mp = sum(-(-c // 256) * 256 for c in call_chains) / len(call_chains)
+        Mc = sum(plan.gemm_rows(c) for c in call_chains) / len(call_chains)   # wide layers: rows of the profiled (last) chunk
         N5 = K1
         layer_flops = [2.0 * Mc * H * K1, 2.0 * Mc * 2 * H * (K1 if folded else H), 2.0 * Mc * 2 * H * 2 * H, 2.0 * Mc * H * 2 * H,
                        2.0 * Mp * N5 * H]
@@ -315,7 +319,7 @@ def main():
             avg_ms = sum(ms[i] / cnt[i] for i in dom) / len(dom)
             avg_flops = sum(layer_flops[i] for i in dom) / len(dom)
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", Mc)
+            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", int(round(Mc)))
             clock = {}
             if a.dtype == "bf16":
                 cyc, us, n = plan.profile_clock()
