@@ -122,6 +122,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's W pieces (and its first fragments) have landed
     __syncthreads();                                             // ... and everyone else's: the only barrier of the kernel
+#ifdef WS_DIAG_HALF                                              /* timing-only diagnostic: one wave per SIMD (row groups of waves 4-7 are skipped) */
+    if (wave >= 4) return;
+#endif
 #ifndef WS_DIAG_NOSLEEP
     if (wave >= 4) __builtin_amdgcn_s_sleep(KT * 8);             // start the second wave of each SIMD ~half a K loop late
 #endif
@@ -140,31 +143,28 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
         // the row group whose fragments are requested next: this wave's next one, or (at the end) the current one again --
         // always a valid address, so the loads need no branch and hipcc can count them exactly in its vmcnt waits
         const int next = tn < n_mine ? rg_of(tn) : rg;
-        // W fragments in groups of four column tiles, read one group (4 x ds_read_b128) ahead of the eight MFMAs that
-        // consume it; the scheduling barriers keep hipcc from hoisting more reads than that (it would spill)
-        constexpr int NG = KS * 4;                               // groups per row group
-        bf16x8 wf[2][4];
-        auto read_w = [&](int g, bf16x8 (&dst)[4]) {
-            const int s = g >> 2, jg = g & 3;
-            const char* wb = wrd[s & 1] + (s >> 1) * (WS_BN * 128) + jg * 4 * 2048;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = *(const bf16x8*)(wb + q * 2048);
+        // W fragments: a ring of eight, each read seven MFMA pairs (~224 MFMA cycles) ahead of the pair that consumes it -- a
+        // group of four read one group ahead (128 cycles) does not cover the LDS latency: K loop 6.2 k cycles for 4.1 k of
+        // MFMAs, measured with one wave per SIMD.  The scheduling barriers keep hipcc from hoisting more reads (it would spill).
+        constexpr int NF = KS * 16, WD = 8;                      // fragments per row group (k-step major, column tile minor)
+        bf16x8 wf[WD];
+        auto read_w = [&](int f) {
+            const int s = f >> 4, j = f & 15;
+            wf[f % WD] = *(const bf16x8*)(wrd[s & 1] + (s >> 1) * (WS_BN * 128) + j * 2048);
         };
-        read_w(0, wf[0]);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int s = g >> 2, jg = g & 3;
-            if (g + 1 < NG) read_w(g + 1, wf[(g + 1) & 1]);
+        for (int f = 0; f < WD - 1; ++f) read_w(f);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int f = 0; f < NF; ++f) {
+            const int s = f >> 4, j = f & 15;
+            if (f + WD - 1 < NF) read_w(f + WD - 1);
 #ifdef WS_DIAG_NOMFMA                                            /* timing-only diagnostic: fragments are read, products skipped */
-                asm volatile("" :: "v"(wf[g & 1][q]), "v"(af[s % RD][0]), "v"(af[s % RD][1]));
-                continue;
+            asm volatile("" :: "v"(wf[f % WD]), "v"(af[s % RD][0]), "v"(af[s % RD][1]));
+#else
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f % WD], af[s % RD][0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f % WD], af[s % RD][1], acc[1][j], 0, 0, 0);
 #endif
-                acc[0][jg * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][q], af[s % RD][0], acc[0][jg * 4 + q], 0, 0, 0);
-                acc[1][jg * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][q], af[s % RD][1], acc[1][jg * 4 + q], 0, 0, 0);
-            }
-            if (jg == 3) {                                       // this ring slot has fed its last MFMA
+            if (j == 15) {                                       // this ring slot has fed its last MFMA
                 if (s + RD < KS) load_a(rg, s + RD, s % RD);
                 else load_a(next, s + RD - KS, s % RD);
             }
@@ -174,33 +174,65 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __res
         WS_STAMP_AT(st_b);
         // ---- epilogue: lane holds out[row t*16 + (lane&15)][col j*16 + 4*(lane>>4) + 0..3]; four chunks of 64 columns ----
         const size_t row0 = (size_t)rg * WS_ROWS;
+        // Eight steps of 16 rows x 64 columns: SiLU the step's four fragments, write them to the transposer, read them back
+        // as whole 128-B rows, store.  The LDS round trip of step i (writes, reads, ~200 cycles) runs under the VALU work of
+        // step i + 1: its stores are placed AFTER that work.  Same-wave LDS operations execute in issue order, so step
+        // i + 1's writes queue behind step i's reads and one staging area is enough.
+        // The bias of a 64-column chunk is read one chunk ahead for the same reason: LDS reads return in order, so a bias
+        // read issued behind a step's transposer traffic would make the next step's first add wait for all of it.
+        uint4 rd0 = make_uint4(0, 0, 0, 0), rd1 = rd0;
+        int pc = 0, pt = 0;                                      // the step whose rows are in rd0 / rd1
+        float4 bv[4], bn[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float4 bv[4];
+        for (int jj = 0; jj < 4; ++jj) bn[jj] = *(const float4*)(bias_lds + jj * 16 + wq * 4);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bv[jj] = *(const float4*)(bias_lds + c * 64 + jj * 16 + wq * 4);
+        for (int step = 0; step < 8; ++step) {
+            const int c = step >> 1, t = step & 1;
+            if (t == 0) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+                for (int jj = 0; jj < 4; ++jj) bv[jj] = bn[jj];
+                if (c < 3) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const f32x4 v = acc[t][c * 4 + jj];
-                    float v0 = v[0] + bv[jj].x, v1 = v[1] + bv[jj].y, v2 = v[2] + bv[jj].z, v3 = v[3] + bv[jj].w;
-                    if (ACT) { silu_fast2(v0, v1); silu_fast2(v2, v3); }
-                    if (OUT_F32)
-                        *(float4*)((char*)out + ((row0 + t * 16) * ldo + n0 + c * 64 + jj * 16) * 4 + o_lane_f32) = make_float4(v0, v1, v2, v3);
-                    else
-                        *(uint2*)(stg + (wa ^ (jj * 32))) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    for (int jj = 0; jj < 4; ++jj) bn[jj] = *(const float4*)(bias_lds + (c + 1) * 64 + jj * 16 + wq * 4);
                 }
-                if (!OUT_F32) {
-                    // same-wave LDS operations execute in issue order: the reads below see the writes above, and the next
-                    // tile's writes cannot pass these reads
+            }
+            uint2 pk[4];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 v = acc[t][c * 4 + jj];
+                float v0 = v[0] + bv[jj].x, v1 = v[1] + bv[jj].y, v2 = v[2] + bv[jj].z, v3 = v[3] + bv[jj].w;
+                if (ACT) { silu_fast2(v0, v1); silu_fast2(v2, v3); }
+                if (OUT_F32)
+                    *(float4*)((char*)out + ((row0 + t * 16) * ldo + n0 + c * 64 + jj * 16) * 4 + o_lane_f32) = make_float4(v0, v1, v2, v3);
+                else
+                    pk[jj] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            }
+            if (!OUT_F32) {
+                __builtin_amdgcn_sched_barrier(0);               // keep the previous step's stores behind this step's arithmetic
+                if (step > 0) {
 #ifdef WS_DIAG_NOSTORE                                           /* timing-only diagnostic: transposed rows are read, not stored */
-                        if (n_rg < 0)
+                    if (n_rg < 0)
 #endif
-                        *(uint4*)((char*)out + ((row0 + t * 16 + q * 8) * ldo + n0 + c * 64) * 2 + o_lane) = *(const uint4*)(stg + ra + q * 1024);
+                    {
+                        *(uint4*)((char*)out + ((row0 + pt * 16) * ldo + n0 + pc * 64) * 2 + o_lane) = rd0;
+                        *(uint4*)((char*)out + ((row0 + pt * 16 + 8) * ldo + n0 + pc * 64) * 2 + o_lane) = rd1;
+                    }
                 }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) *(uint2*)(stg + (wa ^ (jj * 32))) = pk[jj];
+                rd0 = *(const uint4*)(stg + ra);
+                rd1 = *(const uint4*)(stg + ra + 1024);
+                pc = c; pt = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!OUT_F32) {
+#ifdef WS_DIAG_NOSTORE
+            if (n_rg < 0)
+#endif
+            {
+                *(uint4*)((char*)out + ((row0 + pt * 16) * ldo + n0 + pc * 64) * 2 + o_lane) = rd0;
+                *(uint4*)((char*)out + ((row0 + pt * 16 + 8) * ldo + n0 + pc * 64) * 2 + o_lane) = rd1;
             }
         }
 #ifdef WS_STAMP

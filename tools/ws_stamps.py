@@ -23,6 +23,7 @@ a = ap.parse_args()
 _lib.LIB_PATH = os.environ.get("DP_DIAG_LIB", "tools/diag/libdp_ws_stamp.so")
 _lib.SIGNATURES["dp_debug_stamps"] = (C.c_int, [C.c_void_p])
 lib = _lib.load()
+_lib.check(lib.dp_tune(b"ws_gemm", 2), "dp_tune")      # K = 192 / 256 too
 from diffputer_amd.sampler import linear            # noqa: E402
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
