@@ -76,12 +76,16 @@ def csrc_sha() -> str:
     """sha256 over the kernel sources: PMC_TRAFFIC.json is stamped with it (tools/pmc_summary.py --stamp) so counters
     measured on other kernels are never reported as this build's."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(REPO, "diffputer_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")):
+            text = open(os.path.join(d, f), encoding="utf-8").read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # code only: comments and layout do not change counters
+            text = re.sub(r"//[^\n]*", "", text)
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -42,7 +42,8 @@ constexpr int WS_STAGE_WAVE = 2048;                              // epilogue tra
 constexpr int ws_lds_bytes(int kt) { return kt * WS_BN * 128 + 8 * WS_STAGE_WAVE + WS_BN * 4 + 16; }   // W tile | transposers | bias tile | ticket
 
 // KT = K / 64 (1..4).  Grid: a multiple of nbn = N / 256 workgroups, at most one per CU; workgroup b works on column tile
-// b % nbn and takes every (gridDim / nbn)-th group of eight row groups.
+// b % nbn and on the 32-row groups slot, slot + slots, ... (slot = b / nbn, slots = gridDim / nbn), which its eight waves
+// draw one at a time from a ticket counter in LDS.
 template <int KT, bool ACT, bool OUT_F32>
 __global__ __launch_bounds__(WS_THREADS) void k_gemm_bf16_ws(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
