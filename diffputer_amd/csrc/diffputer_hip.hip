@@ -628,8 +628,14 @@ static int impute_impl(dp_plan* p, const float* x_obs, const uint8_t* mask, floa
             const int add_re = j < R - 1;
             const int i_next = std::min((it + 1) / R, S - 1);
             const bool last = no_final && it == n_iter - 1;       // then d_cur, read by this launch cell by cell, receives x_t
-            DP_STEP(k_step_end, g, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re, p->churn[i_next],
-                    p->lv[2 * i_next].c.c_in, last ? w.d_cur : (float*)nullptr, last ? 0 : 1);
+            if (!vec && !noise) {                                 // Philox mode on rows that cannot be walked 16 bytes at a time
+                hipLaunchKernelGGL(k_step_end_grp, dim3(grid_for(M * ((D + 3) / 4))), dim3(256), 0, st, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h,
+                                   p->renoise[i], add_re, p->churn[i_next], p->lv[2 * i_next].c.c_in, last ? w.d_cur : (float*)nullptr, last ? 0 : 1);
+                DP_LAUNCH_CHECK("k_step_end_grp");
+            } else {
+                DP_STEP(k_step_end, g, c, it, l1.c.c_skip, l1.c.c_out, p->t[i + 1], h, p->renoise[i], add_re, p->churn[i_next],
+                        p->lv[2 * i_next].c.c_in, last ? w.d_cur : (float*)nullptr, last ? 0 : 1);
+            }
             if (last)
                 DP_STEP(k_blend_sum, grid_for(n_rows * D / (vec ? 4 : 1)), c, (const float*)w.d_cur, out, (flags & DP_ACCUMULATE) ? 1 : 0);
             if (ev) DP_HIP(hipEventRecord(ev[6], st));

@@ -229,6 +229,56 @@ __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_
     }
 }
 
+// k_step_end for tables whose rows cannot be walked 16 bytes at a time (D % 4 != 0, or unaligned caller tables) in Philox
+// mode: a thread still owns one COLUMN GROUP of one chain (columns 4g .. 4g+3, clipped to D), so the group's Philox blocks
+// are evaluated once instead of once per cell (k_step_end<1> spends 4x the generator work), with 4-byte memory accesses.
+// Same draws, same float32 operations per cell: bit-identical to k_step_end<1> and <4>.
+__global__ __launch_bounds__(256) void k_step_end_grp(StepCommon c, int it, float c_skip, float c_out, float t_next, float h,
+                                                      float renoise, int add_renoise, float churn_next, float c_in_next,
+                                                      float* __restrict__ xt_out, int has_next) {
+    const int G = (c.D + 3) >> 2;
+    const int64_t n_groups = (c.n_cells / c.D) * G;
+    const float inv_t_next = 1.0f / t_next;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_groups; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / G;
+        const int col0 = (int)(idx - m * G) * 4;
+        const int nv = min(4, c.D - col0);
+        const int tl = (int)(m / c.n_rows);
+        const int64_t row = m - (int64_t)tl * c.n_rows;
+        const uint64_t grow = c.row_offset + row;
+        const int gt = c.trial_offset + tl;
+        float gp[4], gr[4] = {0.f, 0.f, 0.f, 0.f}, gc[4] = {0.f, 0.f, 0.f, 0.f};
+        noise_group4(c.seed, grow, gt, col0, (uint32_t)it, 0, gp);
+        if (add_renoise) noise_group4(c.seed, grow, gt, col0, (uint32_t)it, 1, gr);
+        if (has_next) noise_group4(c.seed, grow, gt, col0, (uint32_t)it, 2, gc);
+        const int64_t e0 = m * c.D + col0, oc0 = row * c.D + col0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (v < nv) {
+                const int64_t e = e0 + v;
+                const float xh = c.x_hat[e], d = c.d_cur[e], Fx = c.F[m * c.ldF + col0 + v];
+                const float xo = c.x_obs[oc0 + v], mk = (float)c.mask[oc0 + v];
+                const float xe = xh + h * d;
+                const float den = c_skip * xe + c_out * Fx;
+                const float dp = (xe - den) * inv_t_next;
+                const float xn = xh + h * (0.5f * d + 0.5f * dp);
+                const float xk = xo + gp[v] * t_next;
+                float x_t = xk * (1.0f - mk) + xn * mk;
+                if (add_renoise) x_t = x_t + gr[v] * renoise;
+                if (c.trace) c.trace[(int64_t)it * c.n_cells + e] = x_t;
+                if (xt_out) xt_out[e] = x_t;
+                if (has_next) {
+                    const float xh2 = x_t + churn_next * gc[v];
+                    c.x_hat[e] = xh2;
+                    const float u = c_in_next * xh2;
+                    if (c.u_bf16) ((bf16_t*)c.u)[m * c.ldu + col0 + v] = f2bf(u);
+                    else ((float*)c.u)[m * c.ldu + col0 + v] = u;
+                }
+            }
+        }
+    }
+}
+
 // Last level (t_next = 0): Euler step = the denoised sample; blend; caller's blend; sum over this call's trials.
 // One thread per V cells of (row, col); trials are summed in order, so the result is deterministic.
 template <int V>
