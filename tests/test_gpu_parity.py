@@ -791,3 +791,48 @@ def test_million_row_pass_through_e_step():
     for r in rows.tolist():
         one = estep.impute_trials(plan, X[r:r + 1], mask[r:r + 1], 1, seed=77, row_offset=r)
         assert torch.equal(one[0], out[r]), r
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_gemm_kernel_choice_does_not_change_results(d):
+    """The shallow first layer (folded proj+mlp.0, K = 64 or 256) on the weight-stationary kernel, the ping-pong kernel and
+    the simple kernel: the whole sampler's output is bit-identical (dp_tune "ws_gemm" 0 / 1 / 2, "gemm_variant" 1)."""
+    from diffputer_amd import _lib
+    lib = _lib.load()
+    hid, S, R, n, T = 256, 4, 2, 300, 2
+    sd = synth.make_weights(d, hid, 77, 1.0)
+    X, mask = synth.make_table(n, d, seed=78)
+    x_obs = (X * (1.0 - mask)).astype(np.float32)
+    p = _plan(sd, S, R, "bf16")
+    outs = []
+    try:
+        for ws, variant in ((1, 2), (0, 2), (2, 2), (1, 1)):
+            _lib.check(lib.dp_tune(b"ws_gemm", ws), "dp_tune")
+            _lib.check(lib.dp_tune(b"gemm_variant", variant), "dp_tune")
+            o, _ = p.impute_sum(x_obs, mask, T, seed=5)
+            outs.append(o.clone())
+    finally:
+        _lib.check(lib.dp_tune(b"ws_gemm", 1), "dp_tune")
+        _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+    p.close()
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_profile_clock_samples_the_dominant_kernel():
+    """dp_plan_profile_clock (bench.py's in-kernel clock reading): profiled evaluations of a plan whose mlp.2 runs on the
+    ping-pong kernel yield samples with a shader clock in the chip's range and cycles consistent with the event timing."""
+    d, hid, S, R = 256, 1024, 3, 2
+    p = _plan(synth.make_weights(d, hid, 1, 1.0), S, R, "bf16")
+    X, mask = synth.make_table(8192, d, seed=3)
+    p.profile(1)
+    p.impute_sum((X * (1.0 - mask)).astype(np.float32), mask, 1, seed=1)
+    ms, cnt = p.profile_read()
+    cyc, us, n = p.profile_clock()
+    p.profile(0)
+    p.close()
+    assert n > 0 and cnt[2] == n
+    mhz = cyc / us
+    assert 800.0 < mhz < 2600.0, mhz                                     # MI355X: up to 2.4 GHz, well below it under this kernel
+    assert 0.5 < (us / n) / (ms[2] / cnt[2] * 1e3) < 1.1                 # workgroup 0's lifetime vs the launch's event time
