@@ -309,6 +309,14 @@ def test_philox_mode_equals_replay_of_its_own_field(d):
     a, tra = p.impute_sum(x_obs, mask, T, seed=seed, row_offset=ro, trace=True)
     b, trb = p.impute_sum(x_obs, mask, T, noise=nz, trace=True)
     assert torch.equal(tra, trb) and torch.equal(a, b)
+    # the same without the final level (DP_NO_FINAL_LEVEL: the last end step has no successor and returns x_t itself),
+    # with and without a trace -- for d = 9 the Philox run takes the column-group end step, the replay the per-cell one
+    nz2 = nz[:, : nd - 3].contiguous()
+    a2, tra2 = p.impute_sum(x_obs, mask, T, seed=seed, row_offset=ro, trace=True, final_level=False)
+    b2, trb2 = p.impute_sum(x_obs, mask, T, noise=nz2, trace=True, final_level=False)
+    a3, _ = p.impute_sum(x_obs, mask, T, seed=seed, row_offset=ro, final_level=False)
+    assert torch.equal(tra2, trb2) and torch.equal(a2, b2) and torch.equal(a3, a2)
+    assert torch.equal(tra2, tra[: tra2.shape[0]])                 # the shared levels do not know whether a final one follows
     p.close()
 
 
