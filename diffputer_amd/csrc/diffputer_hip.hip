@@ -621,7 +621,10 @@ static int impute_impl(dp_plan* p, const float* x_obs, const uint8_t* mask, floa
         if ((rc = eval_F(p, w, 2 * i, st, ev, fuse ? &ms : nullptr))) return rc;
         if (i < S - 1) {
             const Level& l1 = p->lv[2 * i + 1];
-            if (!fuse) DP_STEP(k_step_mid, g, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
+            if (!fuse && !vec) {                                  // rows that cannot be walked 16 bytes at a time: one column group per thread
+                hipLaunchKernelGGL(k_step_mid_grp, dim3(grid_for(M * ((D + 3) / 4))), dim3(256), 0, st, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
+                DP_LAUNCH_CHECK("k_step_mid_grp");
+            } else if (!fuse) DP_STEP(k_step_mid, g, c, l0.c.c_skip, l0.c.c_out, p->th[i], h, l1.c.c_in);
             if (ev) DP_HIP(hipEventRecord(ev[6], st));
             ev = prof_slot(p, 1);
             if ((rc = eval_F(p, w, 2 * i + 1, st, ev))) return rc;

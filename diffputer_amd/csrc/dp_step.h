@@ -229,10 +229,63 @@ __global__ __launch_bounds__(256) void k_step_end(StepCommon c, int it, float c_
     }
 }
 
-// k_step_end for tables whose rows cannot be walked 16 bytes at a time (D % 4 != 0, or unaligned caller tables) in Philox
-// mode: a thread still owns one COLUMN GROUP of one chain (columns 4g .. 4g+3, clipped to D), so the group's Philox blocks
-// are evaluated once instead of once per cell (k_step_end<1> spends 4x the generator work), with 4-byte memory accesses.
-// Same draws, same float32 operations per cell: bit-identical to k_step_end<1> and <4>.
+// Step kernels for tables whose rows cannot be walked 16 bytes at a time (D % 4 != 0: california 9, adult 34, news 51; or
+// unaligned caller tables): a thread owns one COLUMN GROUP of one chain (columns 4g .. 4g+3, clipped to D).  In Philox
+// mode the group's blocks are then evaluated once instead of once per cell (the per-cell kernels spend 4x the generator
+// work), and a whole group moves with one 16-byte access that is only 4-byte aligned (gfx950 takes unaligned dwordx4
+// global accesses; F and u are padded to 64 columns, so theirs are aligned).  Same draws and the same float32 operations
+// per cell as k_step_mid / k_step_end: bit-identical results.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct GroupOf { int64_t m, row; int col0, nv, tl; };
+__device__ __forceinline__ GroupOf group_of(const StepCommon& c, int64_t idx, int G) {
+    GroupOf k;
+    k.m = idx / G;
+    k.col0 = (int)(idx - k.m * G) * 4;
+    k.nv = min(4, c.D - k.col0);
+    k.tl = (int)(k.m / c.n_rows);
+    k.row = k.m - (int64_t)k.tl * c.n_rows;
+    return k;
+}
+// 4 (or, for a row's last group, nv < 4) consecutive floats at p
+__device__ __forceinline__ void ld_group(const float* p, int nv, float v[4]) {
+    if (nv == 4) { const f32x4u t = *(const f32x4u*)p; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    else { v[0] = p[0]; v[1] = nv > 1 ? p[1] : 0.f; v[2] = nv > 2 ? p[2] : 0.f; v[3] = 0.f; }
+}
+__device__ __forceinline__ void st_group(float* p, int nv, const float v[4]) {
+    if (nv == 4) { f32x4u t = {v[0], v[1], v[2], v[3]}; *(f32x4u*)p = t; }
+    else { p[0] = v[0]; if (nv > 1) p[1] = v[1]; if (nv > 2) p[2] = v[2]; }
+}
+__device__ __forceinline__ void st_group_u(const StepCommon& c, int64_t m, int col0, int nv, const float v[4]) {
+    if (c.u_bf16) {
+        bf16_t* p = (bf16_t*)c.u + m * c.ldu + col0;             // 8-byte aligned: ldu % 64 == 0, col0 % 4 == 0
+        if (nv == 4) *(uint2*)p = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else { p[0] = f2bf(v[0]); if (nv > 1) p[1] = f2bf(v[1]); if (nv > 2) p[2] = f2bf(v[2]); }
+    } else {
+        float* p = (float*)c.u + m * c.ldu + col0;
+        if (nv == 4) *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        else { p[0] = v[0]; if (nv > 1) p[1] = v[1]; if (nv > 2) p[2] = v[2]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_step_mid_grp(StepCommon c, float c_skip, float c_out, float t_hat, float h, float c_in_next) {
+    const int G = (c.D + 3) >> 2;
+    const int64_t n_groups = (c.n_cells / c.D) * G;
+    const float inv_t_hat = 1.0f / t_hat;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_groups; idx += (int64_t)gridDim.x * blockDim.x) {
+        const GroupOf k = group_of(c, idx, G);
+        const int64_t e0 = k.m * c.D + k.col0;
+        float xh[4], Fx[4], dd[4], uu[4];
+        ld_group(c.x_hat + e0, k.nv, xh);
+        const float4 Fv = *(const float4*)(c.F + k.m * c.ldF + k.col0);       // padded to 64 columns: always 4 readable floats
+        Fx[0] = Fv.x; Fx[1] = Fv.y; Fx[2] = Fv.z; Fx[3] = Fv.w;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) mid_step_cell(xh[v], Fx[v], c_skip, c_out, inv_t_hat, h, c_in_next, dd[v], uu[v]);
+        st_group(c.d_cur + e0, k.nv, dd);
+        st_group_u(c, k.m, k.col0, k.nv, uu);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_step_end_grp(StepCommon c, int it, float c_skip, float c_out, float t_next, float h,
                                                       float renoise, int add_renoise, float churn_next, float c_in_next,
                                                       float* __restrict__ xt_out, int has_next) {
@@ -240,41 +293,41 @@ __global__ __launch_bounds__(256) void k_step_end_grp(StepCommon c, int it, floa
     const int64_t n_groups = (c.n_cells / c.D) * G;
     const float inv_t_next = 1.0f / t_next;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_groups; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = idx / G;
-        const int col0 = (int)(idx - m * G) * 4;
-        const int nv = min(4, c.D - col0);
-        const int tl = (int)(m / c.n_rows);
-        const int64_t row = m - (int64_t)tl * c.n_rows;
-        const uint64_t grow = c.row_offset + row;
-        const int gt = c.trial_offset + tl;
+        const GroupOf k = group_of(c, idx, G);
+        const uint64_t grow = c.row_offset + k.row;
+        const int gt = c.trial_offset + k.tl;
         float gp[4], gr[4] = {0.f, 0.f, 0.f, 0.f}, gc[4] = {0.f, 0.f, 0.f, 0.f};
-        noise_group4(c.seed, grow, gt, col0, (uint32_t)it, 0, gp);
-        if (add_renoise) noise_group4(c.seed, grow, gt, col0, (uint32_t)it, 1, gr);
-        if (has_next) noise_group4(c.seed, grow, gt, col0, (uint32_t)it, 2, gc);
-        const int64_t e0 = m * c.D + col0, oc0 = row * c.D + col0;
+        noise_group4(c.seed, grow, gt, k.col0, (uint32_t)it, 0, gp);
+        if (add_renoise) noise_group4(c.seed, grow, gt, k.col0, (uint32_t)it, 1, gr);
+        if (has_next) noise_group4(c.seed, grow, gt, k.col0, (uint32_t)it, 2, gc);
+        const int64_t e0 = k.m * c.D + k.col0, oc0 = k.row * c.D + k.col0;
+        float xh[4], dv[4], Fx[4], xo[4], mk[4], xt[4], xh2[4], uu[4];
+        ld_group(c.x_hat + e0, k.nv, xh);
+        ld_group(c.d_cur + e0, k.nv, dv);
+        ld_group(c.x_obs + oc0, k.nv, xo);
+        const float4 Fv = *(const float4*)(c.F + k.m * c.ldF + k.col0);
+        Fx[0] = Fv.x; Fx[1] = Fv.y; Fx[2] = Fv.z; Fx[3] = Fv.w;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) mk[v] = v < k.nv ? (float)c.mask[oc0 + v] : 0.f;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            if (v < nv) {
-                const int64_t e = e0 + v;
-                const float xh = c.x_hat[e], d = c.d_cur[e], Fx = c.F[m * c.ldF + col0 + v];
-                const float xo = c.x_obs[oc0 + v], mk = (float)c.mask[oc0 + v];
-                const float xe = xh + h * d;
-                const float den = c_skip * xe + c_out * Fx;
-                const float dp = (xe - den) * inv_t_next;
-                const float xn = xh + h * (0.5f * d + 0.5f * dp);
-                const float xk = xo + gp[v] * t_next;
-                float x_t = xk * (1.0f - mk) + xn * mk;
-                if (add_renoise) x_t = x_t + gr[v] * renoise;
-                if (c.trace) c.trace[(int64_t)it * c.n_cells + e] = x_t;
-                if (xt_out) xt_out[e] = x_t;
-                if (has_next) {
-                    const float xh2 = x_t + churn_next * gc[v];
-                    c.x_hat[e] = xh2;
-                    const float u = c_in_next * xh2;
-                    if (c.u_bf16) ((bf16_t*)c.u)[m * c.ldu + col0 + v] = f2bf(u);
-                    else ((float*)c.u)[m * c.ldu + col0 + v] = u;
-                }
-            }
+            const float d = dv[v];
+            const float xe = xh[v] + h * d;
+            const float den = c_skip * xe + c_out * Fx[v];
+            const float dp = (xe - den) * inv_t_next;
+            const float xn = xh[v] + h * (0.5f * d + 0.5f * dp);
+            const float xk = xo[v] + gp[v] * t_next;
+            float x_t = xk * (1.0f - mk[v]) + xn * mk[v];
+            if (add_renoise) x_t = x_t + gr[v] * renoise;
+            xt[v] = x_t;
+            xh2[v] = x_t + churn_next * gc[v];
+            uu[v] = c_in_next * xh2[v];
+        }
+        if (c.trace) st_group(c.trace + (int64_t)it * c.n_cells + e0, k.nv, xt);
+        if (xt_out) st_group(xt_out + e0, k.nv, xt);
+        if (has_next) {
+            st_group(c.x_hat + e0, k.nv, xh2);
+            st_group_u(c, k.m, k.col0, k.nv, uu);
         }
     }
 }
