@@ -313,17 +313,26 @@ def main():
                 per[nm] = {"avg_ms": ms[i] / cnt[i], "samples": cnt[i]}
                 if i < 5:
                     per[nm]["tflops"] = layer_flops[i] / (ms[i] / cnt[i] * 1e-3) / 1e12
-        # dominant kernel: the SiLU / bf16-out GEMM = the (proj+)mlp.0, mlp.2, mlp.4 launches (one of each per evaluation);
-        # achieved = executed FLOPs of those launches / their in-situ duration
-        # (a shallow first layer, K <= 128, runs on the weight-stationary kernel instead: then the dominant kernel's launches
-        # are mlp.2 and mlp.4 only)
+        # dominant kernel: the SiLU / bf16-out GEMM of the deep layers = the mlp.2 and mlp.4 launches (one of each per
+        # evaluation; K = 2 hid) on the four-wave kernel, plus mlp.0 when it is not folded (K = hid); the folded proj+mlp.0
+        # (K = padded table width) runs on the weight-stationary or the ping-pong kernel and is listed under "kernels".
+        # achieved = executed FLOPs of those launches / their in-situ duration.  --tune gemm_variant=2: all three on the
+        # ping-pong kernel, as before round 2's four-wave kernel.
+        variant = int(dict(kv.split("=", 1) for kv in a.tune).get("gemm_variant", 3))
         k_first = K1 if folded else H
-        dom = (1, 2, 3) if (a.dtype != "bf16" or k_first > 128) else (2, 3)
+        if a.dtype != "bf16":
+            dom, dom_name = (1, 2, 3), "k_gemm_f32<SiLU>"
+        elif variant == 3 and 2 * H >= 1024:
+            dom = (1, 2, 3) if k_first >= 1024 else (2, 3)
+            dom_name, pmc_name = "k_gemm_bf16_w4<SiLU>", "dp::k_gemm_bf16_w4<true>"
+        else:
+            dom = (1, 2, 3) if k_first > 128 else (2, 3)
+            dom_name, pmc_name = "k_gemm_bf16_pp<SiLU,bf16-out>", "dp::k_gemm_bf16_pp<true, 0>"
         if all(cnt[i] for i in dom):
             avg_ms = sum(ms[i] / cnt[i] for i in dom) / len(dom)
             avg_flops = sum(layer_flops[i] for i in dom) / len(dom)
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic("dp::k_gemm_bf16_pp<true, 0>" if a.dtype == "bf16" else "dp::k_gemm_f32<true>", int(round(Mc)))
+            traffic, traffic_src = pmc_traffic(pmc_name if a.dtype == "bf16" else "dp::k_gemm_f32<true>", int(round(Mc)))
             clock = {}
             if a.dtype == "bf16":
                 cyc, us, n = plan.profile_clock()
@@ -337,7 +346,7 @@ def main():
                                            "1024 FLOP per cycle (v_mfma_f32_16x16x32_bf16: 16 384 FLOP per 16 cycles); the 2.5 PFLOP/s peak assumes 2.4 GHz"}
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **clock,
                                   "traffic_source": traffic_src,
-                                  "kernel": ("k_gemm_bf16_pp<SiLU,bf16-out> (" + (("proj+mlp.0, " if folded else "mlp.0, ") if 1 in dom else "") + "mlp.2, mlp.4)") if a.dtype == "bf16" else "k_gemm_f32<SiLU>",
+                                  "kernel": (dom_name + " (" + (("proj+mlp.0, " if folded else "mlp.0, ") if 1 in dom else "") + "mlp.2, mlp.4)") if a.dtype == "bf16" else dom_name,
                                   "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mc}
         # fused step kernel (after the 2nd evaluation): algorithmic bytes per cell = x_hat r/w 8 + d_cur 4 + F 4 + x_obs 4 + mask 1 + u 2
         if cnt[6]:

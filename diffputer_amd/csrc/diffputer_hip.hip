@@ -12,6 +12,7 @@
 #include "dp_gemm_bf16.h"
 #include "dp_gemm_bf16_pp.h"
 #include "dp_gemm_bf16_ws.h"
+#include "dp_gemm_bf16_w4.h"
 #include "dp_gemm_f32.h"
 #include "dp_philox.h"
 #include "dp_prep.h"
@@ -82,11 +83,12 @@ static int grid_for(int64_t n, int block = 256, int cap = 2048) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// tuning knobs (dp_tune): "gemm_variant" 2 = ping-pong kernel for the wide layers (default), 1 = k_gemm_bf16 everywhere;
+// tuning knobs (dp_tune): "gemm_variant" 3 = four-wave kernel for the deep layers, ping-pong kernel for the other wide ones
+// (default), 2 = ping-pong kernel for all wide layers, 1 = k_gemm_bf16 everywhere;
 // "fold_proj" 1 = evaluate proj and mlp.0 as one Linear (default), 0 = as two GEMMs like the reference's module list.
 // Process-wide and read once per evaluation; relaxed atomics, so a dp_tune on one thread never tears a read on another
 // (include/diffputer.h, "Threading").
-static std::atomic<int> g_gemm_variant{2};
+static std::atomic<int> g_gemm_variant{3};
 static std::atomic<int> g_fold_proj{1};
 static std::atomic<int> g_m_chunk{32768};  // "m_chunk": rows per launch of the wide layers in bf16 plans (0 = whole batch), see eval_F
 static std::atomic<int> g_ws_gemm{1};      // "ws_gemm": weight-stationary kernel for shallow layers with N % 256 == 0 (bf16 plans):
@@ -140,6 +142,23 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     else DP_GO(true, EPI_F32);
 #undef DP_GO
     DP_LAUNCH_CHECK("k_gemm_bf16_pp");
+    return DP_OK;
+}
+
+// "gemm_variant" 3 (default): the four-wave kernel (dp_gemm_bf16_w4.h) for the deep bf16-out layers (K >= 1024, K % 128 == 0,
+// N <= 4096); the ping-pong kernel keeps the rest (float32 output, the fused mid step, K < 1024)
+static int launch_bf16_w4(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
+                          int act, hipStream_t st, unsigned long long* clk = nullptr) {
+    const int nbn = N / 256;
+    const int64_t nwg64 = (M / 256) * nbn;
+    if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
+    const int nwg = (int)nwg64;
+    const DeviceState* ds = device_state();
+    if (!ds) return DP_EHIP;
+    const int grid = std::min(nwg, ds->num_cus);
+    if (act) hipLaunchKernelGGL((k_gemm_bf16_w4<true>), dim3(grid), dim3(W4_THREADS), W4_LDS_TOTAL, st, A, W, bias, (bf16_t*)out, ldo, K, N, nwg, clk);
+    else hipLaunchKernelGGL((k_gemm_bf16_w4<false>), dim3(grid), dim3(W4_THREADS), W4_LDS_TOTAL, st, A, W, bias, (bf16_t*)out, ldo, K, N, nwg, clk);
+    DP_LAUNCH_CHECK("k_gemm_bf16_w4");
     return DP_OK;
 }
 
@@ -209,6 +228,8 @@ static int ensure_device_ready(int dev) {
     DP_ATTR((k_gemm_bf16_pp<true, EPI_F32>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_pp<false, EPI_F32>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_pp<false, EPI_MID>), PP_LDS_TOTAL);
+    DP_ATTR((k_gemm_bf16_w4<true>), W4_LDS_TOTAL);
+    DP_ATTR((k_gemm_bf16_w4<false>), W4_LDS_TOTAL);
 #define DP_ATTR4(BM, BN, WM, WN)                                                                  \
     DP_ATTR((k_gemm_bf16<BM, BN, WM, WN, true, false>), (gemm_bf16_lds_bytes<BM, BN>()));        \
     DP_ATTR((k_gemm_bf16<BM, BN, WM, WN, false, false>), (gemm_bf16_lds_bytes<BM, BN>()));       \
@@ -239,9 +260,11 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
         const int ws = tune(g_ws_gemm);
-        if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && tune(g_gemm_variant) == 2)
+        if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && tune(g_gemm_variant) >= 2)
             return launch_bf16_ws((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
-        if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) == 2)
+        if (N % 256 == 0 && N <= W4_MAX_N && K >= 1024 && K % 128 == 0 && !out_f32 && tune(g_gemm_variant) == 3)
+            return launch_bf16_w4((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, st, clk);
+        if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) >= 2)
             return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
         if (N % 256 == 0)
             return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
@@ -285,7 +308,7 @@ static Workspace carve(const dp_plan* p, int64_t M, void* base) {
 static bool folded(const dp_plan* p) { return tune(g_fold_proj) && p->dtype == DP_DTYPE_BF16; }
 // the step after a Heun iteration's first evaluation runs in mlp.6's epilogue when that GEMM's tile spans the whole row
 static bool mid_fused(const dp_plan* p) {
-    return tune(g_fuse_mid) && tune(g_gemm_variant) == 2 && p->dtype == DP_DTYPE_BF16 && p->d_in == 256 && p->hid >= 3 * PP_BK;
+    return tune(g_fuse_mid) && tune(g_gemm_variant) >= 2 && p->dtype == DP_DTYPE_BF16 && p->d_in == 256 && p->hid >= 3 * PP_BK;
 }
 
 // ---- one denoiser evaluation F(u, level): the Linear layers as GEMMs with fused epilogues (model.py:121-128) ------
@@ -854,7 +877,7 @@ int64_t dp_plan_gemm_rows(const dp_plan* plan, int64_t n_chains) {
 int dp_tune(const char* key, int value) {
     if (!key) return fail(DP_EINVAL, "key is NULL");
     if (!strcmp(key, "gemm_variant")) {
-        if (value < 1 || value > 2) return fail(DP_EINVAL, "gemm_variant must be 1 or 2");
+        if (value < 1 || value > 3) return fail(DP_EINVAL, "gemm_variant must be 1, 2 or 3");
         g_gemm_variant = value;
         return DP_OK;
     }

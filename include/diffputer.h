@@ -189,8 +189,9 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
 
 /*
  * Process-wide tuning knobs for benchmarks and A/B tools (no counterpart in the reference).  Keys:
- *   "gemm_variant"  2 = ping-pong 256x256 kernel for the wide layers (default), 1 = the simple double-buffered
- *                   kernel everywhere; results are bit-identical.
+ *   "gemm_variant"  3 (default) = four-wave 256x256 kernel for the deep bf16-output layers (K >= 1024), ping-pong 256x256
+ *                   kernel for the other wide ones; 2 = ping-pong kernel for all wide layers; 1 = the simple
+ *                   double-buffered kernel everywhere; results are bit-identical.
  *   "fold_proj"     1 (default) = in DP_DTYPE_BF16 plans proj and mlp.0 run as ONE Linear, (W0 Wp) u + (W0 (proj.bias + emb) + b0): no
  *                   activation separates them (model.py:126-128), so this is the same function with one rounding
  *                   of h0 fewer; 0 = two GEMMs as in the reference's module list.  Read at every evaluation.

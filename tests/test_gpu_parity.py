@@ -72,10 +72,12 @@ def test_linear_bf16(M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K", [(16384, 2048, 256), (256 * 33, 2048, 192), (256 * 70, 1024, 512), (256 * 3, 256, 1024),
-                                   (256 * 35, 2048, 64), (256, 256, 128), (256 * 9, 512, 256), (256 * 131, 1024, 64)])
+                                   (256 * 35, 2048, 64), (256, 256, 128), (256 * 9, 512, 256), (256 * 131, 1024, 64),
+                                   (256 * 67, 2048, 2048), (256 * 131, 1024, 2048), (256, 4096, 1152), (256 * 40, 2048, 1024)])
 def test_linear_bf16_persistent(M, N, K):
     """The persistent kernels beyond one tile per workgroup: whole rounds, a ragged last round, fewer tiles than CUs --
-    the ping-pong kernel (K >= 192... with K > 256) and the weight-stationary kernel (K <= 256: every K-tile count, more
+    the four-wave kernel (bf16 output, K >= 1024: "gemm_variant" 3, the default), the ping-pong kernel (K >= 192; float32
+    output; everything wide under "gemm_variant" 2) and the weight-stationary kernel (K <= 256: every K-tile count, more
     and fewer row groups than waves, 1 to 8 column tiles).
     Checker: torch fp32 matmul of the same bf16 operands on the device; and the simple kernel, bit for bit."""
     from diffputer_amd import _lib
@@ -89,18 +91,22 @@ def test_linear_bf16_persistent(M, N, K):
     outs = {}
     _lib.check(lib.dp_tune(b"ws_gemm", 2), "dp_tune")                  # K <= 256 -> weight-stationary kernel, else ping-pong
     try:
-        for variant in (2, 1):
+        for variant in (3, 2, 1):
             _lib.check(lib.dp_tune(b"gemm_variant", variant), "dp_tune")
             outs[variant] = linear(A, W, b, act=True)
             outs[(variant, "f32")] = linear(A, W, b, act=True, out_f32=True)
+            outs[(variant, "noact")] = linear(A, W, b, act=False)
         _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
         if 192 <= K <= 256:                                          # both persistent kernels take these shapes
             _lib.check(lib.dp_tune(b"ws_gemm", 0), "dp_tune")
             assert torch.equal(linear(A, W, b, act=True), outs[2])
     finally:
-        _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+        _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
         _lib.check(lib.dp_tune(b"ws_gemm", 1), "dp_tune")
-    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[(2, "f32")], outs[(1, "f32")])
+    for variant in (3, 2):
+        for kind in (None, "f32", "noact"):
+            key = lambda v: v if kind is None else (v, kind)
+            assert torch.equal(outs[key(variant)], outs[key(1)]), (variant, kind)
     assert torch.allclose(outs[2].float(), ref, rtol=1e-2, atol=1e-2), (outs[2].float() - ref).abs().max()
     assert torch.allclose(outs[(2, "f32")], ref, rtol=2e-3, atol=2e-3), (outs[(2, "f32")] - ref).abs().max()
 
@@ -814,14 +820,14 @@ def test_gemm_kernel_choice_does_not_change_results(d):
     p = _plan(sd, S, R, "bf16")
     outs = []
     try:
-        for ws, variant in ((1, 2), (0, 2), (2, 2), (1, 1)):
+        for ws, variant in ((1, 3), (1, 2), (0, 2), (2, 2), (1, 1)):
             _lib.check(lib.dp_tune(b"ws_gemm", ws), "dp_tune")
             _lib.check(lib.dp_tune(b"gemm_variant", variant), "dp_tune")
             o, _ = p.impute_sum(x_obs, mask, T, seed=5)
             outs.append(o.clone())
     finally:
         _lib.check(lib.dp_tune(b"ws_gemm", 1), "dp_tune")
-        _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+        _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
     p.close()
     assert torch.isfinite(outs[0]).all()
     for o in outs[1:]:
