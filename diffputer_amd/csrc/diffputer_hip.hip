@@ -93,6 +93,7 @@ static std::atomic<int> g_fold_proj{1};
 static std::atomic<int> g_m_chunk{32768};  // "m_chunk": rows per launch of the wide layers in bf16 plans (0 = whole batch), see eval_F
 static std::atomic<int> g_ws_gemm{1};      // "ws_gemm": weight-stationary kernel for shallow layers with N % 256 == 0 (bf16 plans):
                                            // 1 = where it wins, K <= 128 (default); 2 = wherever it runs, K <= 256; 0 = never
+static std::atomic<int> g_w4_min_k{1024};  // "w4_min_k": smallest K the four-wave kernel takes under gemm_variant 3 (A/B knob; >= 256)
 static std::atomic<int> g_fuse_mid{1};     // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 static inline int tune(const std::atomic<int>& v) { return v.load(std::memory_order_relaxed); }
 
@@ -262,7 +263,7 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
         const int ws = tune(g_ws_gemm);
         if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && tune(g_gemm_variant) >= 2)
             return launch_bf16_ws((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
-        if (N % 256 == 0 && N <= W4_MAX_N && K >= 1024 && K % 128 == 0 && !out_f32 && tune(g_gemm_variant) == 3)
+        if (N % 256 == 0 && N <= W4_MAX_N && K >= tune(g_w4_min_k) && K % 128 == 0 && !out_f32 && tune(g_gemm_variant) == 3)
             return launch_bf16_w4((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, st, clk);
         if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) >= 2)
             return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
@@ -879,6 +880,11 @@ int dp_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_variant")) {
         if (value < 1 || value > 3) return fail(DP_EINVAL, "gemm_variant must be 1, 2 or 3");
         g_gemm_variant = value;
+        return DP_OK;
+    }
+    if (!strcmp(key, "w4_min_k")) {
+        if (value < 256) return fail(DP_EINVAL, "w4_min_k must be >= 256");
+        g_w4_min_k = value;
         return DP_OK;
     }
     if (!strcmp(key, "ws_gemm")) {

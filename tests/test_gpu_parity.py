@@ -100,9 +100,16 @@ def test_linear_bf16_persistent(M, N, K):
         if 192 <= K <= 256:                                          # both persistent kernels take these shapes
             _lib.check(lib.dp_tune(b"ws_gemm", 0), "dp_tune")
             assert torch.equal(linear(A, W, b, act=True), outs[2])
+        if K >= 256 and K % 128 == 0 and N <= 4096:                  # the four-wave kernel on its shortest K loops (4, 8 K-tiles)
+            _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
+            _lib.check(lib.dp_tune(b"ws_gemm", 0), "dp_tune")
+            _lib.check(lib.dp_tune(b"w4_min_k", 256), "dp_tune")
+            assert torch.equal(linear(A, W, b, act=True), outs[1])
+            assert torch.equal(linear(A, W, b, act=False), outs[(1, "noact")])
     finally:
         _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
         _lib.check(lib.dp_tune(b"ws_gemm", 1), "dp_tune")
+        _lib.check(lib.dp_tune(b"w4_min_k", 1024), "dp_tune")
     for variant in (3, 2):
         for kind in (None, "f32", "noact"):
             key = lambda v: v if kind is None else (v, kind)

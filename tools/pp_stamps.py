@@ -20,12 +20,15 @@ ap.add_argument("--m", type=int, default=65536)
 ap.add_argument("--n", type=int, default=2048)
 ap.add_argument("--k", type=int, default=2048)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--w4-min-k", type=int, default=1024)
 ap.add_argument("--variant", type=int, default=2, help="dp_tune gemm_variant: 2 = ping-pong kernel, 3 = four-wave kernel")
 a = ap.parse_args()
 ap2 = os.environ.get("DP_DIAG_LIB", os.path.join(REPO, "tools", "diag", "libdiffputer_hip_stamp.so"))
 lib = C.CDLL(ap2)
 lib.dp_last_error.restype = C.c_char_p
 assert lib.dp_tune(b"gemm_variant", a.variant) == 0, lib.dp_last_error()
+assert lib.dp_tune(b"w4_min_k", a.w4_min_k) == 0, lib.dp_last_error()
+assert lib.dp_tune(b"ws_gemm", 0) == 0, lib.dp_last_error()
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 A = torch.randn(a.m, a.k, device=dev, generator=g).bfloat16()
