@@ -324,7 +324,9 @@ def test_mstep_loss_and_gradient_match_reference():
 
 def test_pingpong_gemm_counted_waits_match_the_emitted_code():
     """tools/check_pp_asm.py: the vmcnt(8 + NST) / vmcnt(10 + NST) waits of k_gemm_bf16_pp assume NST epilogue stores sit
-    behind the next tile's prologue DMA; compile the kernel and count them in the gfx950 assembly (also: no scratch)."""
+    behind the next tile's prologue DMA; compile the kernel and count them in the gfx950 assembly (also: no scratch).
+    The same for k_gemm_bf16_w4: 4 DMA instructions per phase, 32 epilogue stores, vmcnt(24) / vmcnt(56), every M0 write an
+    MFMA ahead of its DMA, no scratch access, no vmcnt(0) inside the tile loop."""
     import subprocess
     import sys
     if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
