@@ -78,11 +78,6 @@ __global__ __launch_bounds__(W4_THREADS) void k_gemm_bf16_w4(const bf16_t* __res
         clk[2] = __builtin_amdgcn_s_memrealtime();
     }
 
-    // bias -> LDS (before any DMA is in flight: the compiler's wait for these loads drains nothing)
-    for (int c = tid * 4; c < N; c += W4_THREADS * 4)
-        *(float4*)(smem + W4_BIAS_OFF + c * 4) = *(const float4*)(bias + c);
-    __syncthreads();
-
     // ---- staging: a wave moves pieces wave, wave+4, wave+8, wave+12 of a half-tile (piece = 8 rows x 128 B) ----
     //   piece p = half-local rows 8p..: wave row/col p/8, rows h*64 + (p%8)*8.. of its 128.  Source address = the half's
     //   first byte (SGPR pair) + a 32-bit lane offset that carries the piece's row offset (vq[q]).
@@ -196,8 +191,12 @@ __global__ __launch_bounds__(W4_THREADS) void k_gemm_bf16_w4(const bf16_t* __res
     stage_half(c3.a, 4, 0); stage_half(c3.w, 6, 0); stage_half(c3.w, 7, 1);
     c2 = c3;                                                     // K-tile 1
     advance(c3);                                                 // K-tile 2
-    DP_VMCNT(24);                                                // A0(0)
-    __builtin_amdgcn_s_barrier();
+    // bias -> LDS, behind the first seven half-tiles: the compiler's wait for these loads (and its drain of the DMA before
+    // a visible LDS store) is the wait for the first half-tiles the stream needs anyway -- one memory latency, not two
+    for (int c = tid * 4; c < N; c += W4_THREADS * 4)
+        *(float4*)(smem + W4_BIAS_OFF + c * 4) = *(const float4*)(bias + c);
+    DP_VMCNT(0);
+    __syncthreads();
     // pseudo-phases p2(-1), p3(-1)
 #pragma unroll
     for (int r = 0; r < 8; ++r) W4_READ1(a0, a_ad[0][0], r);
