@@ -5,6 +5,7 @@
 //   mode 8: one wave per SIMD, the weight-stationary kernel's K loop: per MFMA pair one ds_read_b128 into a ring of 8 that the
 //           pair 7 ahead consumes, s_waitcnt lgkmcnt(7) before each pair     mode 9: as 8 without the waits (fragments not consumed)
 //   mode 10: as 8 with the MFMA wave's partner (second wave of the SIMD) running the VALU mix
+//   modes 11, 12: as 8, 10 with the accumulators in AGPRs
 //   mode 6: as 2 with the roles swapped (the OLDER wave does the VALU work)   mode 7: as 6, MFMA wave at s_setprio 3
 // Prints shader cycles per iteration (s_memtime of wave 0) for each mode.  One workgroup per CU, all CUs.
 #include <hip/hip_runtime.h>
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(512) void probe(int mode, int iters, unsigned long 
 }
 
 // the weight-stationary kernel's K loop on one wave per SIMD (waves 0-3); waves 4-7 run the VALU mix when VALU_PARTNER
-template <bool WAIT, bool VALU_PARTNER>
+template <bool WAIT, bool VALU_PARTNER, bool AGPR>
 __global__ __launch_bounds__(512) void probe_ws(int iters, unsigned long long* cyc, float* sink) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     const int wave = threadIdx.x >> 6;
@@ -94,8 +95,13 @@ __global__ __launch_bounds__(512) void probe_ws(int iters, unsigned long long* c
             for (int p = 0; p < 8; ++p) {
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[(p + 7) & 7]) : "v"(ad), "n"(1024 * (p + 1)));
                 if (WAIT) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(2 * p) & 7]) : "v"(WAIT ? ring[p] : a), "v"(b));
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(2 * p + 1) & 7]) : "v"(WAIT ? ring[p] : a), "v"(b));
+                if (AGPR) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(2 * p) & 7]) : "v"(WAIT ? ring[p] : a), "v"(b));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(2 * p + 1) & 7]) : "v"(WAIT ? ring[p] : a), "v"(b));
+                } else {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(2 * p) & 7]) : "v"(WAIT ? ring[p] : a), "v"(b));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(2 * p + 1) & 7]) : "v"(WAIT ? ring[p] : a), "v"(b));
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -131,12 +137,14 @@ int main() {
     const int iters = 20000;
     std::vector<unsigned long long> h(cus * 8);
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 11; ++mode) {
+        for (int mode = 0; mode < 13; ++mode) {
             if (mode >= 8) {
                 hipMemset(cyc, 0, cus * 8 * sizeof(unsigned long long));
-                if (mode == 8) hipLaunchKernelGGL((probe_ws<true, false>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
-                if (mode == 9) hipLaunchKernelGGL((probe_ws<false, false>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
-                if (mode == 10) hipLaunchKernelGGL((probe_ws<true, true>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
+                if (mode == 8) hipLaunchKernelGGL((probe_ws<true, false, false>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
+                if (mode == 9) hipLaunchKernelGGL((probe_ws<false, false, false>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
+                if (mode == 11) hipLaunchKernelGGL((probe_ws<true, false, true>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
+                if (mode == 12) hipLaunchKernelGGL((probe_ws<true, true, true>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
+                if (mode == 10) hipLaunchKernelGGL((probe_ws<true, true, false>), dim3(cus), dim3(512), 0, 0, iters, cyc, sink);
                 if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
                 hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                 if (rep) printf("mode %d: wave 0 (first of its SIMD) %.1f cycles / iteration, wave 4 (second) %.1f\n", mode, (double)h[0] / iters, (double)h[4] / iters);
