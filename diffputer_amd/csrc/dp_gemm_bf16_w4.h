@@ -272,7 +272,9 @@ __global__ __launch_bounds__(W4_THREADS) void k_gemm_bf16_w4(const bf16_t* __res
                      : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])                                       \
                      : "a"(acc[(s) >> 2][(s) & 3][hb][j][0]), "a"(acc[(s) >> 2][(s) & 3][hb][j][1]),            \
                        "a"(acc[(s) >> 2][(s) & 3][hb][j][2]), "a"(acc[(s) >> 2][(s) & 3][hb][j][3]));           \
-        float v0 = c[0] + bv[hb][j].x, v1 = c[1] + bv[hb][j].y, v2 = c[2] + bv[hb][j].z, v3 = c[3] + bv[hb][j].w; \
+        const f32x2_t s01 = (f32x2_t){c[0], c[1]} + (f32x2_t){bv[hb][j].x, bv[hb][j].y};  /* packed adds: same bits */ \
+        const f32x2_t s23 = (f32x2_t){c[2], c[3]} + (f32x2_t){bv[hb][j].z, bv[hb][j].w};                         \
+        float v0 = s01.x, v1 = s01.y, v2 = s23.x, v3 = s23.y;                                                   \
         if (ACT) { silu_fast2(v0, v1); silu_fast2(v2, v3); }                                                    \
         pk[hb * 4 + j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                  \
     }
