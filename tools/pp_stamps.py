@@ -119,5 +119,9 @@ if rounds > 1:
     dc = s[:, rounds - 1, 0, 3] - s[:, 0, 0, 3]
     dr = s[:, rounds - 1, 0, 4] - s[:, 0, 0, 4]
     print(f"in-kernel clock: {np.median(dc / dr) * 100:.0f} MHz")
+    mhz = dc / dr * 100
+    cyc = s[:, rounds - 1, 0, 3] - s[:, 0, 0, 0]
+    print("per-XCD clock [MHz]:  " + " ".join(f"{np.median(mhz[x::8]):.0f}" for x in range(8)))
+    print("per-XCD cycles [k]:   " + " ".join(f"{np.median(cyc[x::8]) / 1e3:.1f}" for x in range(8)))
 nk = a.k // 64
 print(f"ideal MFMA cycles per tile: {nk * 4 * 512}")
