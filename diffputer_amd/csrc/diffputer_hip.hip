@@ -94,6 +94,8 @@ static std::atomic<int> g_m_chunk{32768};  // "m_chunk": rows per launch of the 
 static std::atomic<int> g_ws_gemm{1};      // "ws_gemm": weight-stationary kernel for shallow layers with N % 256 == 0 (bf16 plans):
                                            // 1 = where it wins, K <= 128 (default); 2 = wherever it runs, K <= 256; 0 = never
 static std::atomic<int> g_w4_min_k{1024};  // "w4_min_k": smallest K the four-wave kernel takes under gemm_variant 3 (A/B knob; >= 256)
+static std::atomic<int> g_narrow_bm{128};   // "narrow_bm": rows per tile of the simple kernel on layers with N % 256 != 0 (mlp.6 of narrow tables): 128
+                                           // (default: 512 tiles of 48 KiB LDS keep three workgroups per CU loading; the layer is bound by reading h3) or 256
 static std::atomic<int> g_fuse_mid{1};     // "fuse_mid": 1 = k_step_mid runs inside the mlp.6 GEMM when d_in = 256 (bf16 plans)
 static inline int tune(const std::atomic<int>& v) { return v.load(std::memory_order_relaxed); }
 
@@ -238,6 +240,7 @@ static int ensure_device_ready(int dev) {
     DP_ATTR((k_gemm_bf16<BM, BN, WM, WN, false, true>), (gemm_bf16_lds_bytes<BM, BN>()))
     DP_ATTR4(256, 256, 2, 4);
     DP_ATTR4(256, 64, 4, 1);
+    DP_ATTR4(128, 64, 4, 1);
 #undef DP_ATTR4
 #define DP_ATTR_WS(KT)                                                                            \
     DP_ATTR((k_gemm_bf16_ws<KT, true, false>), ws_lds_bytes(KT));                                 \
@@ -269,6 +272,8 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
             return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
         if (N % 256 == 0)
             return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
+        if (tune(g_narrow_bm) == 128)
+            return launch_bf16_cfg<128, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
         return launch_bf16_cfg<256, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
     }
     if (dtype != DP_DTYPE_F32) return fail(DP_EINVAL, "unknown dtype %d", dtype);
@@ -880,6 +885,11 @@ int dp_tune(const char* key, int value) {
     if (!strcmp(key, "gemm_variant")) {
         if (value < 1 || value > 3) return fail(DP_EINVAL, "gemm_variant must be 1, 2 or 3");
         g_gemm_variant = value;
+        return DP_OK;
+    }
+    if (!strcmp(key, "narrow_bm")) {
+        if (value != 128 && value != 256) return fail(DP_EINVAL, "narrow_bm must be 128 or 256");
+        g_narrow_bm = value;
         return DP_OK;
     }
     if (!strcmp(key, "w4_min_k")) {

@@ -192,6 +192,8 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
  *   "gemm_variant"  3 (default) = four-wave 256x256 kernel for the deep bf16-output layers (K >= 1024), ping-pong 256x256
  *                   kernel for the other wide ones; 2 = ping-pong kernel for all wide layers; 1 = the simple
  *                   double-buffered kernel everywhere; results are bit-identical.
+ *   "narrow_bm"     rows per tile of the simple kernel on layers with N % 256 != 0 (mlp.6 of tables narrower than 256
+ *                   columns): 128 (default) or 256; the layer is bound by reading its input, smaller tiles keep more loads in flight.
  *   "w4_min_k"      smallest K the four-wave kernel takes under "gemm_variant" 3 (default 1024, at least 256; it needs
  *                   K % 128 == 0, N % 256 == 0, N <= 4096 and bf16 output): below 1024 the ping-pong kernel is as fast or faster.
  *   "fold_proj"     1 (default) = in DP_DTYPE_BF16 plans proj and mlp.0 run as ONE Linear, (W0 Wp) u + (W0 (proj.bias + emb) + b0): no
