@@ -817,7 +817,8 @@ def test_million_row_pass_through_e_step():
 @pytest.mark.parametrize("d", [64, 256])
 def test_gemm_kernel_choice_does_not_change_results(d):
     """The shallow first layer (folded proj+mlp.0, K = 64 or 256) on the weight-stationary kernel, the ping-pong kernel and
-    the simple kernel: the whole sampler's output is bit-identical (dp_tune "ws_gemm" 0 / 1 / 2, "gemm_variant" 1)."""
+    the simple kernel, the deep layers on the four-wave or the ping-pong kernel, the narrow last layer on 128- or 256-row tiles:
+    the whole sampler's output is bit-identical (dp_tune "ws_gemm" 0 / 1 / 2, "gemm_variant" 1 / 2 / 3, "narrow_bm")."""
     from diffputer_amd import _lib
     lib = _lib.load()
     hid, S, R, n, T = 256, 4, 2, 300, 2
@@ -827,12 +828,14 @@ def test_gemm_kernel_choice_does_not_change_results(d):
     p = _plan(sd, S, R, "bf16")
     outs = []
     try:
-        for ws, variant in ((1, 3), (1, 2), (0, 2), (2, 2), (1, 1)):
+        for ws, variant, narrow in ((1, 3, 128), (1, 3, 256), (1, 2, 128), (0, 2, 128), (2, 2, 128), (1, 1, 128)):
             _lib.check(lib.dp_tune(b"ws_gemm", ws), "dp_tune")
             _lib.check(lib.dp_tune(b"gemm_variant", variant), "dp_tune")
+            _lib.check(lib.dp_tune(b"narrow_bm", narrow), "dp_tune")     # tile height of the narrow last layer (d = 64: N = 64)
             o, _ = p.impute_sum(x_obs, mask, T, seed=5)
             outs.append(o.clone())
     finally:
+        _lib.check(lib.dp_tune(b"narrow_bm", 128), "dp_tune")
         _lib.check(lib.dp_tune(b"ws_gemm", 1), "dp_tune")
         _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
     p.close()
