@@ -54,8 +54,35 @@ def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, b
     return model, best
 
 
+_WAIT_GROUPS: dict = {}
+
+
+def trainer_wait_group(days: float = 7.0):
+    """A gloo (host-side) process group over all ranks with a timeout of `days`, created once per process (collective: every
+    rank must call it).  The M-step runs on ONE rank for up to 10 001 epochs (main.py:100) -- hours on the large tables --
+    while the default timeout of a device collective is 10 minutes (RCCL) / 30 (gloo): ranks that simply entered the weight
+    broadcast would be aborted by the watchdog long before the trainer arrives.  They wait here instead, on the host."""
+    import datetime
+
+    import torch.distributed as dist
+    key = dist.get_world_size()
+    if key not in _WAIT_GROUPS:
+        _WAIT_GROUPS[key] = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=days))
+    return _WAIT_GROUPS[key]
+
+
+def wait_for_trainer(loss: float, src: int = 0, group=None) -> float:
+    """Host-side rendezvous after the M-step: returns rank `src`'s loss on every rank once `src` has finished training.
+    No device collective is pending while the others wait."""
+    import torch.distributed as dist
+    box = torch.tensor([loss], dtype=torch.float64)                         # CPU tensor on the gloo group
+    dist.broadcast(box, src=src, group=group if group is not None else trainer_wait_group())
+    return float(box.item())
+
+
 def broadcast_model(model, loss: float, src: int = 0):
-    """Every rank leaves with rank `src`'s parameters (in place, tensor by tensor in state-dict order) and its loss."""
+    """Every rank leaves with rank `src`'s parameters (in place, tensor by tensor in state-dict order) and its loss.
+    Call it when every rank is ready (after `wait_for_trainer`): these are device collectives with the default timeout."""
     import torch.distributed as dist
     for t in model.state_dict().values():
         dist.broadcast(t, src=src)
@@ -92,6 +119,7 @@ def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, m
     X = torch.as_tensor(X).to(dev, torch.float32).contiguous()
     m_tr = torch.as_tensor(mask_train).to(dev).contiguous()
     gen = torch.Generator(device=dev).manual_seed(seed)
+    wait_group = trainer_wait_group() if distributed else None
     res = EMResult()
     train_data = (1.0 - m_tr.float()) * X                                     # iteration 0: zero-filled (main.py:84-86)
     for it in range(max_iter):
@@ -101,6 +129,7 @@ def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, m
         else:
             model, loss = Model(denoise_fn=MLPDiffusion(X.shape[1], hid_dim), hid_dim=X.shape[1]).to(dev).eval(), 0.0
         if distributed:
+            loss = wait_for_trainer(loss, src=0, group=wait_group)           # host-side: may take hours
             model, loss = broadcast_model(model, loss, src=0)
         res.train_loss.append(loss)
         if ckpt_dir and rank == 0:

@@ -240,6 +240,38 @@ def test_impute_bf16_trajectory(name, fold):
     assert np.array_equal(out[obs], g["x_obs"][obs])
 
 
+def test_reference_written_checkpoint_drives_the_sampler():
+    """SURVEY.md §8 f3 interchange: a `model.pt` the reference wrote with `torch.save(model.state_dict())` (main.py:142;
+    tests/golden/model_ref_H64.pt from tools/make_ckpt_golden.py) is read by formats.load_checkpoint (weights_only=True) and
+    drives SamplerPlan to what the reference's own impute_mask made of the same file: every per-iteration x_t within 1e-3
+    relative in float32, observed cells bit for bit; bf16 within the trajectory bound."""
+    import os
+    from conftest import GOLDEN
+    from diffputer_amd import formats
+    from diffputer_amd.sampler import SamplerPlan
+    g = load_golden("model_ref_H64_io")
+    sd = formats.load_checkpoint(os.path.join(GOLDEN, "model_ref_H64.pt"))
+    assert sorted(sd) == [str(k) for k in g["keys"]]
+    S, R = int(g["S"]), int(g["R"])
+    noise = golden_noise(g)
+    p = SamplerPlan(sd, num_steps=S, n_resample=R, dtype="f32", device=DEV)
+    out, tr = p.impute_sum(g["x_obs"], g["mask"], 1, noise=noise, trace=True)
+    t = p.schedule()
+    p.close()
+    out, tr = out.cpu().numpy(), tr[:, 0].cpu().numpy()
+    for k, ref in enumerate(g["trace"]):
+        lvl = min(k // R, S - 1)
+        sig = float(t[lvl + 1]) if (k % R == R - 1 or lvl == S - 1) else float(t[lvl])
+        rel_check(tr[k], ref, floor=max(1e-2 * sig, 1e-3), what=f"reference checkpoint, iteration {k}")
+    rel_check(out, g["out"], floor=1e-3, what="reference checkpoint, final")
+    obs = ~g["mask"]
+    assert np.array_equal(out[obs], g["x_obs"][obs])
+    p = SamplerPlan(sd, num_steps=S, n_resample=R, dtype="bf16", device=DEV)
+    got, _ = p.impute_sum(g["x_obs"], g["mask"], 1, noise=noise)
+    p.close()
+    assert float(np.abs(got.cpu().numpy() - g["out"]).max()) <= 2e-2
+
+
 def test_estep_trial_mean_golden():
     from diffputer_amd.sampler import SamplerPlan  # noqa: F401
     g = load_golden("estep_D9_H64_S5_T3")

@@ -189,6 +189,91 @@ def test_e_step_world_size_2_gloo(shard):
     assert res == [(0, True, (n, d)), (1, True, (n, d))]
 
 
+def _local_estep_worker(rank, world, port, n, d, T, gather, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    estep.plan_for = lambda *a, **k: _FakePlan()
+    r0, r1 = estep.shard_bounds(n, world, rank)
+    X = torch.zeros(r1 - r0, d)                          # this rank holds ONLY its own rows of the table
+    mask = torch.zeros(r1 - r0, d, dtype=torch.bool)
+    got = estep.e_step(None, X, mask, num_trials=T, device="cpu", max_chains=16, local_rows=(r0, r1), n_rows=n, gather=gather)
+    want = (torch.arange(n, dtype=torch.float32)[:, None] + sum(t / 64.0 for t in range(T)) / T).expand(n, d)
+    if gather == "rank0" and rank != 0:
+        ok, shape = got is None, None
+    else:
+        ok, shape = bool(torch.allclose(got, want, rtol=1e-6, atol=0)), tuple(got.shape)
+    bad = False
+    if rank == 1:                                         # a shard that is not this rank's shard_bounds block is refused
+        try:
+            estep.e_step(None, X, mask, num_trials=T, device="cpu", local_rows=(r0 - 1, r1 - 1), n_rows=n)
+        except ValueError:
+            bad = True
+    q.put((rank, ok, shape, bad))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,gather", [(13, True), (13, "rank0"), (12, True), (3, True)])
+def test_e_step_shard_local_inputs_world_size_2_gloo(n, gather):
+    """every rank passes only its own rows (uneven shards: 13 = 7 + 6); the shard's result is written into the
+    block the collective sends and the gathered table is compacted in place -- on every rank, or on rank 0 only."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    d, T = 3, 5
+    procs = [ctx.Process(target=_local_estep_worker, args=(r, 2, port, n, d, T, gather, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    other = None if gather == "rank0" else (n, d)
+    assert res == [(0, True, (n, d), False), (1, True, other, True)]
+
+
+def _slow_trainer_worker(rank, world, port, q):
+    import datetime
+    import time
+    import torch.distributed as dist
+    from diffputer_amd import em, prep
+    from diffputer_amd.evalmetrics import mae_rmse
+    # a process group whose collectives give up after 3 s, and an M-step that takes 7 s on rank 0
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=3))
+    estep.plan_for = lambda *a, **k: _FakePlan()
+    prep.masked_errors = lambda pred, truth, m, num_num=None, drop_rows=None: mae_rmse(pred.numpy(), truth.numpy(), m.numpy())
+    real = em.m_step
+
+    def slow(*a, **k):
+        time.sleep(7.0)
+        return real(*a, **k)
+
+    em.m_step = slow
+    X, mask = synth.make_table(32, 4, seed=1)
+    t0 = time.time()
+    try:
+        res = em.run_em(X, mask, hid_dim=64, max_iter=1, num_trials=1, num_steps=5, device="cpu", max_epochs=1, log=lambda *_: None)
+        q.put((rank, "ok", len(res.train_loss), time.time() - t0 >= 6.5))
+    except Exception as e:                                # noqa: BLE001 -- reported to the parent
+        q.put((rank, f"{type(e).__name__}: {e}"[:200], 0, False))
+    dist.destroy_process_group()
+
+
+def test_run_em_trainer_outlasts_the_process_group_timeout():
+    """rank 0's M-step takes longer than the process group's collective timeout.  The other rank must
+    not sit in a collective of that group meanwhile: it waits on em.trainer_wait_group (host side, week-long timeout)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slow_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, "ok", 1, True), (1, "ok", 1, True)], res
+
+
 def _em_worker(rank, world, port, ckpt_dir, q):
     import torch.distributed as dist
     from diffputer_amd import em, prep

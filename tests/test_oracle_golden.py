@@ -188,3 +188,24 @@ def test_variants_sample_and_missdiff():
     g = load_golden("missdiff_D9_H64_S10")
     out = orc.impute_mask(sd, g["x_obs"], g["mask"], g["noise"], int(g["S"]), int(g["R"]), final_level=False)
     close(out, g["out"], atol=1e-5, rtol=1e-4)
+
+
+def test_reference_written_checkpoint():
+    """tests/golden/model_ref_H64.pt is a file the REFERENCE wrote (`torch.save(model.state_dict())`,
+    main.py:142, tools/make_ckpt_golden.py).  formats.load_checkpoint (weights_only=True: nothing in the file is executed)
+    must read it, and the oracle driven by it must reproduce what the reference's own impute_mask made of the reloaded file."""
+    import os
+    from conftest import GOLDEN
+    from diffputer_amd import formats
+    g = load_golden("model_ref_H64_io")
+    sd = formats.load_checkpoint(os.path.join(GOLDEN, "model_ref_H64.pt"))
+    assert sorted(sd) == [str(k) for k in g["keys"]] and len(sd) == 14
+    assert all(v.dtype.is_floating_point and v.element_size() == 4 for v in sd.values())
+    sd = {k: v.numpy() for k, v in sd.items()}
+    noise = golden_noise(g)
+    trace = []
+    out = orc.impute_mask(sd, g["x_obs"], g["mask"], noise, int(g["S"]), int(g["R"]), trace)
+    close(out, g["out"], atol=1e-5)
+    t = orc.sigma_schedule(int(g["S"]))
+    for k, ref in enumerate(g["trace"]):
+        close(trace[k], ref, atol=1e-5 * max(1.0, float(t[min(k // int(g["R"]), int(g["S"]) - 1)])))
