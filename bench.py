@@ -51,6 +51,11 @@ def cpu_baseline(d, hid, S, R, T, rows, budget_note):
     (what the reference's sampler runs on: `addmm` on torch's BLAS, torch's SiLU), oracle/diffputer_oracle_torch.py."""
     from oracle import diffputer_oracle_torch as orct                     # the only place bench.py touches oracle/
     cores = torch.get_num_threads()
+    try:                                                                  # physical cores of the host, beside the threads used
+        import psutil
+        phys, logical = psutil.cpu_count(logical=False), psutil.cpu_count(logical=True)
+    except Exception:                                                     # noqa: BLE001
+        phys, logical = None, os.cpu_count()
     sd = synth.make_weights(d, hid, seed=11, gain=1.0)
     X, mask = synth.make_table(rows, d, seed=12)
     x_obs = (X * (1.0 - mask)).astype(np.float32)
@@ -66,7 +71,8 @@ def cpu_baseline(d, hid, S, R, T, rows, budget_note):
     orct.impute_mask(sd, x_obs, mask, LazyNoise(), S, R)
     dt = time.perf_counter() - t0
     row_trials_per_s = rows / dt
-    return {"value": row_trials_per_s / T, "unit": "rows/s", "cores": cores, "kind": "port",
+    return {"value": row_trials_per_s / T, "unit": "rows/s", "cores": cores, "host_physical_cores": phys, "host_logical_cpus": logical,
+            "kind": "port",
             "sample": f"{rows} rows x 1 trial, full S={S}/R={R} schedule, D={d}, H={hid}, float32 port on torch CPU operators "
                       f"({dt:.1f} s on {cores} threads; rows/s = row-trials/s / T={T}){budget_note}",
             "row_trials_per_s": row_trials_per_s}
@@ -318,21 +324,19 @@ def main():
         # (K = padded table width) runs on the weight-stationary or the ping-pong kernel and is listed under "kernels".
         # achieved = executed FLOPs of those launches / their in-situ duration.  --tune gemm_variant=2: all three on the
         # ping-pong kernel, as before round 2's four-wave kernel.
-        variant = int(dict(kv.split("=", 1) for kv in a.tune).get("gemm_variant", 3))
-        k_first = K1 if folded else H
-        if a.dtype != "bf16":
-            dom, dom_name = (1, 2, 3), "k_gemm_f32<SiLU>"
-        elif variant == 3 and 2 * H >= 1024:
-            dom = (1, 2, 3) if k_first >= 1024 else (2, 3)
-            dom_name, pmc_name = "k_gemm_bf16_w4<SiLU>", "dp::k_gemm_bf16_w4<true>"
-        else:
-            dom = (1, 2, 3) if k_first > 128 else (2, 3)
-            dom_name, pmc_name = "k_gemm_bf16_pp<SiLU,bf16-out>", "dp::k_gemm_bf16_pp<true, 0>"
+        # The kernel of each slot is asked of the library (its own dispatch predicate under the current dp_tune settings).
+        slot_kernel = [plan.gemm_kernel(i) for i in range(5)]
+        pmc_names = {"k_gemm_bf16_w4": "dp::k_gemm_bf16_w4<true>", "k_gemm_bf16_pp": "dp::k_gemm_bf16_pp<true, 0>",
+                     "k_gemm_bf16_ws": None, "k_gemm_f32": "dp::k_gemm_f32<true>"}
+        dom_kernel = slot_kernel[2]                                        # mlp.2: half of the FLOPs
+        dom = tuple(i for i in (1, 2, 3) if slot_kernel[i] == dom_kernel)
+        dom_name = dom_kernel + "<SiLU>"
+        pmc_name = pmc_names.get(dom_kernel)
         if all(cnt[i] for i in dom):
             avg_ms = sum(ms[i] / cnt[i] for i in dom) / len(dom)
             avg_flops = sum(layer_flops[i] for i in dom) / len(dom)
             ach = avg_flops / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(pmc_name if a.dtype == "bf16" else "dp::k_gemm_f32<true>", int(round(Mc)))
+            traffic, traffic_src = pmc_traffic(pmc_name, int(round(Mc))) if pmc_name else (None, "no PMC summary for this kernel")
             clock = {}
             if a.dtype == "bf16":
                 cyc, us, n = plan.profile_clock()
@@ -346,7 +350,8 @@ def main():
                                            "1024 FLOP per cycle (v_mfma_f32_16x16x32_bf16: 16 384 FLOP per 16 cycles); the 2.5 PFLOP/s peak assumes 2.4 GHz"}
             result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **clock,
                                   "traffic_source": traffic_src,
-                                  "kernel": (dom_name + " (" + (("proj+mlp.0, " if folded else "mlp.0, ") if 1 in dom else "") + "mlp.2, mlp.4)") if a.dtype == "bf16" else dom_name,
+                                  "kernel": dom_name + " (" + ", ".join({1: "proj+mlp.0" if folded else "mlp.0", 2: "mlp.2", 3: "mlp.4"}[i] for i in dom) + ")",
+                                  "slot_kernels": dict(zip(["proj", "mlp0", "mlp2", "mlp4", "mlp6"], slot_kernel)),
                                   "avg_launch_ms": avg_ms, "alg_flops_per_launch": avg_flops, "rows_per_launch": Mc}
         # fused step kernel (after the 2nd evaluation): algorithmic bytes per cell = x_hat r/w 8 + d_cur 4 + F 4 + x_obs 4 + mask 1 + u 2
         if cnt[6]:

@@ -38,6 +38,7 @@ SIGNATURES = {
     "dp_plan_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "dp_plan_profile_clock": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     "dp_plan_gemm_rows": (_i64, [_vp, _i64]),
+    "dp_plan_gemm_kernel": (C.c_char_p, [_vp, _i]),
     "dp_tune": (_i, [C.c_char_p, _i]),
     "dp_linear": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "dp_masked_mean_std": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -108,7 +108,12 @@ static __device__ __align__(256) unsigned char scratch[DP_STATIC_SCRATCH_BYTES];
 // persistent kernel's grid, the dynamic-LDS attribute of every GEMM variant, the address of this device's scratch array.
 // Filled once per device under a mutex, by dp_plan_create (or by the first dp_linear on a device that has no plan), with
 // that device current; afterwards read-only, so launches take no lock and make no set-up call.
-struct DeviceState { std::atomic<int> ready{0}; int num_cus = 0; void* scratch = nullptr; };
+struct DeviceState {
+    std::atomic<int> ready{0};
+    int num_cus = 0;
+    void* scratch = nullptr;
+    std::string lds_err;     // non-empty: a GEMM variant could not get its dynamic-LDS window on this device (raised when a bf16 GEMM is launched)
+};
 static DeviceState g_dev[64];
 static std::mutex g_dev_mutex;
 static int current_device() {
@@ -122,6 +127,12 @@ static const DeviceState* device_state() {
     if (!g_dev[dev].ready.load(std::memory_order_acquire) && ensure_device_ready(dev) != DP_OK) return nullptr;
     return &g_dev[dev];
 }
+// for the bf16 GEMM launchers: the device state, or NULL (error set) when the LDS attributes could not be set on this device
+static const DeviceState* device_state_bf16() {
+    const DeviceState* ds = device_state();
+    if (ds && !ds->lds_err.empty()) { fail(DP_EHIP, "%s", ds->lds_err.c_str()); return nullptr; }
+    return ds;
+}
 
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
                           int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr, unsigned long long* clk = nullptr) {
@@ -129,7 +140,7 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     const int64_t nwg64 = (M / PP_BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
-    const DeviceState* ds = device_state();
+    const DeviceState* ds = device_state_bf16();
     if (!ds) return DP_EHIP;
     const int num_cus = ds->num_cus;
     MidStep ms = mid ? *mid : MidStep{};
@@ -156,7 +167,7 @@ static int launch_bf16_w4(const bf16_t* A, const bf16_t* W, const float* bias, v
     const int64_t nwg64 = (M / 256) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
-    const DeviceState* ds = device_state();
+    const DeviceState* ds = device_state_bf16();
     if (!ds) return DP_EHIP;
     const int grid = std::min(nwg, ds->num_cus);
     if (act) hipLaunchKernelGGL((k_gemm_bf16_w4<true>), dim3(grid), dim3(W4_THREADS), W4_LDS_TOTAL, st, A, W, bias, (bf16_t*)out, ldo, K, N, nwg, clk);
@@ -173,7 +184,7 @@ static int launch_bf16_cfg(const bf16_t* A, const bf16_t* W, const float* bias, 
     const int64_t nwg64 = (M / BM) * nbn;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
-    if (!device_state()) return DP_EHIP;
+    if (!device_state_bf16()) return DP_EHIP;
 #define DP_GO(ACT, OF)                                                                                              \
     hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM, WN, ACT, OF>), dim3(nwg), dim3(WM* WN * 64), LDS, st, A, W, bias, out, ldo, K, nbn, nwg)
     if (act && !out_f32) DP_GO(true, false);
@@ -188,7 +199,7 @@ static int launch_bf16_cfg(const bf16_t* A, const bf16_t* W, const float* bias, 
 // K <= 256: the weight-stationary kernel (dp_gemm_bf16_ws.h)
 static int launch_bf16_ws(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
                           int act, int out_f32, hipStream_t st) {
-    const DeviceState* ds = device_state();
+    const DeviceState* ds = device_state_bf16();
     if (!ds) return DP_EHIP;
     const int nbn = N / WS_BN;
     const int64_t n_rg64 = M / WS_ROWS;
@@ -225,7 +236,16 @@ static int ensure_device_ready(int dev) {
     hipDeviceProp_t prop;
     DP_HIP(hipGetDeviceProperties(&prop, dev));
     d.num_cus = prop.multiProcessorCount;
-#define DP_ATTR(kern, bytes) DP_HIP(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)))
+    // a failure here (a device with a smaller LDS) must not take float32 plans down with it: it is recorded and raised by
+    // the first bf16 GEMM launch on this device
+#define DP_ATTR(kern, bytes)                                                                                              \
+    do {                                                                                                                  \
+        hipError_t e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));    \
+        if (e_ != hipSuccess && d.lds_err.empty()) {                                                                      \
+            (void)hipGetLastError();                                                                                      \
+            d.lds_err = std::string("hipFuncSetAttribute(" #kern ", ") + std::to_string((int)(bytes)) + " bytes of dynamic LDS) failed: " + hipGetErrorString(e_); \
+        }                                                                                                                 \
+    } while (0)
     DP_ATTR((k_gemm_bf16_pp<true, EPI_BF16>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_pp<false, EPI_BF16>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_pp<true, EPI_F32>), PP_LDS_TOTAL);
@@ -258,23 +278,46 @@ static int ensure_device_ready(int dev) {
     return DP_OK;
 }
 
+// Which kernel runs act(A W^T + b) of shape [*, K] -> [*, N]: ONE predicate, used by gemm() and by dp_plan_gemm_kernel
+// (bench.py labels its roofline with what actually ran).
+enum GemmKernel { GK_F32, GK_WS, GK_W4, GK_PP, GK_SIMPLE, GK_NARROW128, GK_NARROW256, GK_NONE };
+static GemmKernel pick_gemm(int dtype, int N, int K, int out_f32) {
+    if (dtype == DP_DTYPE_F32) return GK_F32;
+    if (dtype != DP_DTYPE_BF16) return GK_NONE;
+    const int ws = tune(g_ws_gemm), variant = tune(g_gemm_variant);
+    if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && variant >= 2) return GK_WS;
+    if (N % 256 == 0 && N <= W4_MAX_N && K >= tune(g_w4_min_k) && K % 128 == 0 && !out_f32 && variant == 3) return GK_W4;
+    if (N % 256 == 0 && K >= 3 * PP_BK && variant >= 2) return GK_PP;
+    if (N % 256 == 0) return GK_SIMPLE;
+    return tune(g_narrow_bm) == 128 ? GK_NARROW128 : GK_NARROW256;
+}
+static const char* gemm_kernel_name(GemmKernel k) {
+    switch (k) {
+        case GK_F32: return "k_gemm_f32";
+        case GK_WS: return "k_gemm_bf16_ws";
+        case GK_W4: return "k_gemm_bf16_w4";
+        case GK_PP: return "k_gemm_bf16_pp";
+        case GK_SIMPLE: return "k_gemm_bf16<256,256>";
+        case GK_NARROW128: return "k_gemm_bf16<128,64>";
+        case GK_NARROW256: return "k_gemm_bf16<256,64>";
+        default: return "";
+    }
+}
+
 static int gemm(int dtype, const void* A, const void* W, const float* bias, void* out, int ldo, int64_t M, int N, int K, int act,
                 int out_f32, hipStream_t st, unsigned long long* clk = nullptr) {
     if (M <= 0 || M % 256 || N <= 0 || N % 64 || K <= 0 || K % 64)
         return fail(DP_EINVAL, "gemm shape M=%lld N=%d K=%d: need M%%256==0, N%%64==0, K%%64==0", (long long)M, N, K);
     if (dtype == DP_DTYPE_BF16) {
-        const int ws = tune(g_ws_gemm);
-        if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && tune(g_gemm_variant) >= 2)
-            return launch_bf16_ws((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
-        if (N % 256 == 0 && N <= W4_MAX_N && K >= tune(g_w4_min_k) && K % 128 == 0 && !out_f32 && tune(g_gemm_variant) == 3)
-            return launch_bf16_w4((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, st, clk);
-        if (N % 256 == 0 && K >= 3 * PP_BK && tune(g_gemm_variant) >= 2)
-            return launch_bf16_pp((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
-        if (N % 256 == 0)
-            return launch_bf16_cfg<256, 256, 2, 4>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
-        if (tune(g_narrow_bm) == 128)
-            return launch_bf16_cfg<128, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
-        return launch_bf16_cfg<256, 64, 4, 1>((const bf16_t*)A, (const bf16_t*)W, bias, out, ldo, M, N, K, act, out_f32, st);
+        const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W;
+        switch (pick_gemm(dtype, N, K, out_f32)) {
+            case GK_WS: return launch_bf16_ws(a, w, bias, out, ldo, M, N, K, act, out_f32, st);
+            case GK_W4: return launch_bf16_w4(a, w, bias, out, ldo, M, N, K, act, st, clk);
+            case GK_PP: return launch_bf16_pp(a, w, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
+            case GK_SIMPLE: return launch_bf16_cfg<256, 256, 2, 4>(a, w, bias, out, ldo, M, N, K, act, out_f32, st);
+            case GK_NARROW128: return launch_bf16_cfg<128, 64, 4, 1>(a, w, bias, out, ldo, M, N, K, act, out_f32, st);
+            default: return launch_bf16_cfg<256, 64, 4, 1>(a, w, bias, out, ldo, M, N, K, act, out_f32, st);
+        }
     }
     if (dtype != DP_DTYPE_F32) return fail(DP_EINVAL, "unknown dtype %d", dtype);
     const int nbn = N / 64;
@@ -712,13 +755,25 @@ int dp_plan_profile(dp_plan* p, int stride) {
     int rc = check_plan(p, false);
     if (rc) return rc;
     if (stride < 0) return fail(DP_EINVAL, "stride must be >= 0");
-    if (stride && p->prof_ev.empty()) {
-        p->prof_ev.resize((size_t)7 * DP_PROF_SAMPLES);
+    if (stride && (p->prof_ev.empty() || !p->prof_clk)) {
+        free_plan_events(p);                                       // a half-built set from an earlier failure
         p->prof_tag.assign(DP_PROF_SAMPLES, 0);
-        for (auto& e : p->prof_ev) DP_HIP(hipEventCreate(&e));
-        DP_HIP(hipMalloc((void**)&p->prof_clk, (size_t)DP_PROF_SAMPLES * 4 * sizeof(unsigned long long)));
+        p->prof_ev.reserve((size_t)7 * DP_PROF_SAMPLES);
+        for (int i = 0; i < 7 * DP_PROF_SAMPLES; ++i) {
+            hipEvent_t e;
+            hipError_t err = hipEventCreate(&e);
+            if (err != hipSuccess) { free_plan_events(p); return fail(DP_EHIP, "hipEventCreate failed: %s", hipGetErrorString(err)); }
+            p->prof_ev.push_back(e);
+        }
+        hipError_t err = hipMalloc((void**)&p->prof_clk, (size_t)DP_PROF_SAMPLES * 4 * sizeof(unsigned long long));
+        if (err != hipSuccess) { p->prof_clk = nullptr; free_plan_events(p); return fail(DP_EHIP, "hipMalloc(prof_clk) failed: %s", hipGetErrorString(err)); }
     }
-    if (stride) DP_HIP(hipMemset(p->prof_clk, 0, (size_t)DP_PROF_SAMPLES * 4 * sizeof(unsigned long long)));
+    if (stride) {
+        // a profiled launch of an earlier call may still be running on the caller's stream and would write its clock words
+        // after a null-stream memset: wait for the device, then clear
+        DP_HIP(hipDeviceSynchronize());
+        DP_HIP(hipMemset(p->prof_clk, 0, (size_t)DP_PROF_SAMPLES * 4 * sizeof(unsigned long long)));
+    }
     p->prof_stride = stride;
     p->prof_evals = 0;
     p->prof_used = 0;
@@ -757,7 +812,7 @@ int dp_plan_profile_clock(dp_plan* p, double* cycles_sum, double* wall_us_sum, i
     DP_HIP(hipMemcpy(h.data(), p->prof_clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int s = 0; s < p->prof_used; ++s) {
         const unsigned long long c0 = h[4 * s], c1 = h[4 * s + 1], r0 = h[4 * s + 2], r1 = h[4 * s + 3];
-        if (c1 <= c0 || r1 <= r0) continue;                        // no ping-pong mlp.2 launch in this sample (narrow plan, f32)
+        if (c1 <= c0 || r1 <= r0) continue;                        // mlp.2 of this sample ran on a kernel without the clock hook (narrow plan, f32)
         *cycles_sum += (double)(c1 - c0);
         *wall_us_sum += (double)(r1 - r0) * 0.01;                   // s_memrealtime ticks at 100 MHz
         *count += 1;
@@ -878,6 +933,19 @@ int dp_debug_stamps(void* buf) {
 int64_t dp_plan_gemm_rows(const dp_plan* plan, int64_t n_chains) {
     if (!plan || n_chains <= 0) return 0;
     return chunk_rows(plan, round_up<int64_t>(n_chains, 256));
+}
+
+const char* dp_plan_gemm_kernel(const dp_plan* p, int layer) {
+    if (!p || layer < 0 || layer > 4) { fail(DP_EINVAL, "dp_plan_gemm_kernel: bad plan or layer"); return ""; }
+    const int H = p->hid;
+    const bool fold = folded(p);
+    switch (layer) {
+        case 0: return fold ? "" : gemm_kernel_name(pick_gemm(p->dtype, H, p->K1, 0));
+        case 1: return gemm_kernel_name(pick_gemm(p->dtype, 2 * H, fold ? p->K1 : H, 0));
+        case 2: return gemm_kernel_name(pick_gemm(p->dtype, 2 * H, 2 * H, 0));
+        case 3: return gemm_kernel_name(pick_gemm(p->dtype, H, 2 * H, 0));
+        default: return mid_fused(p) ? "k_gemm_bf16_pp" : gemm_kernel_name(pick_gemm(p->dtype, p->N5, H, 1));
+    }
 }
 
 int dp_tune(const char* key, int value) {

@@ -23,7 +23,8 @@
 //   * the K-tile stream does not stop at an output tile's end: the stage cursor walks on into the workgroup's next tile
 //     (persistent, tile = round * gridDim + xcd_remap), so the epilogue runs with seven half-tiles of the next tile in
 //     flight and the first fragments of the next tile already in registers.  Past the workgroup's last tile the cursor
-//     wraps to its first one: those loads land in slots nobody reads again and keep every wait a counted one.  For six
+//     parks on the first K-tile of its first one: those loads land in slots nobody reads again and keep every wait a
+//     counted one (they re-read one 32-KiB pair of half-tiles instead of streaming on).  For six
 //     phases after an epilogue its W4_NST stores sit between the half-tiles in the in-order vmcnt queue: vmcnt(24 + NST).
 //   * the phase body is inline asm throughout (MFMA with its accumulator pinned to AGPRs, ds_read_b128, the DMA with its
 //     M0 write one MFMA earlier, the waits): hipcc's own schedule of the same loop spills accumulators, and its waits for
@@ -98,15 +99,18 @@ __global__ __launch_bounds__(W4_THREADS) void k_gemm_bf16_w4(const bf16_t* __res
     struct Cur { const char* a; const char* w; int kt, tile; };
     const int tile0 = xcd_remap(blockIdx.x, G);                  // host guarantees G <= nwg
     auto cur_tile = [&](Cur& c, int tile) {
-        if (tile >= nwg) tile = tile0;                           // past the end: harmless re-loads (see above)
-        c.tile = tile; c.kt = 0;
+        // past the end: the cursor parks on K-tile 0 of the workgroup's first tile (kt = nk keeps advance() from moving
+        // it): the seven half-tiles still to be issued re-load the same 2 x 16 KiB instead of walking 112 KiB further
+        const bool dead = tile >= nwg;
+        if (dead) tile = tile0;
+        c.tile = dead ? nwg : tile; c.kt = dead ? nk : 0;
         const int m0 = __builtin_amdgcn_readfirstlane((tile / nbn) * 256), n0 = __builtin_amdgcn_readfirstlane((tile % nbn) * 256);
         c.a = (const char*)A + (size_t)m0 * K * 2;
         c.w = (const char*)W + (size_t)n0 * K * 2;
     };
     auto advance = [&](Cur& c) {
         if (c.kt + 1 < nk) { ++c.kt; c.a += 128; c.w += 128; }
-        else cur_tile(c, c.tile + G);
+        else if (c.kt < nk) cur_tile(c, c.tile + G);             // kt == nk: parked past the end
     };
 
     // ---- fragment reads: address registers per (buffer, half, k-step); + i * 2048 as the instruction's offset ----

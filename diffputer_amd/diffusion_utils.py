@@ -30,6 +30,7 @@ S_noise = 1
 N_RESAMPLE = 20            # the local `N = 20` of diffusion_utils.py:37
 
 _default_dtype = "bf16"
+_bf16_notice_given = False
 _seed_counter = itertools.count(int(np.random.SeedSequence().generate_state(1)[0]))
 _plans: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
@@ -55,6 +56,14 @@ def plan_for(net, num_steps: int, device, dtype: str | None = None, n_resample: 
     rebuilds the model and reloads model.pt for every trial (main.py:170-173); here the packed
     weights are reused until a parameter changes."""
     _check_net(net)
+    global _bf16_notice_given
+    if dtype is None and _default_dtype == "bf16" and not _bf16_notice_given:
+        # the reference is float32 end to end (model.py:150-153); a drop-in that changes the arithmetic says so, once
+        import logging
+        logging.getLogger("diffputer_amd").warning(
+            "impute_mask / sample_step run the denoiser's GEMMs with bf16 operands (float32 accumulate, float32 sampler state); "
+            "the reference computes in float32 -- call diffusion_utils.set_default_dtype('f32') or pass dtype='f32' for that path")
+        _bf16_notice_given = True
     dtype = dtype or _default_dtype
     dev = torch.device(device)
     params = list(net.parameters())

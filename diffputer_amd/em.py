@@ -49,6 +49,8 @@ def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, b
                 break
         if log and epoch % 100 == 0:
             log(f"  epoch {epoch}: loss {cur:.4f} (best {best:.4f})")
+    if best_sd is None:                                     # every epoch's loss was NaN / inf (e.g. a constant column: std 0 in main.py:58)
+        raise FloatingPointError("M-step: the training loss was never finite; check the normalised table for NaN / inf")
     model.load_state_dict(best_sd)
     model.eval()
     return model, best

@@ -144,6 +144,11 @@ class SamplerPlan:
         """Rows per launch of the wide-layer GEMMs for a call of `n_chains` chains (dp_tune "m_chunk")."""
         return int(self.lib.dp_plan_gemm_rows(self._h, int(n_chains)))
 
+    def gemm_kernel(self, layer: int) -> str:
+        """Kernel that runs profile slot `layer` (0 proj, 1 mlp.0 / folded proj+mlp.0, 2 mlp.2, 3 mlp.4, 4 mlp.6) under the current
+        dp_tune settings -- the library's own dispatch predicate (dp_plan_gemm_kernel); '' for a slot that launches nothing."""
+        return (self.lib.dp_plan_gemm_kernel(self._h, int(layer)) or b"").decode()
+
     # -- the sampler ---------------------------------------------------------------------------------------
     def _prep(self, x_obs, mask):
         x = torch.as_tensor(x_obs).to(self.device, torch.float32).contiguous()

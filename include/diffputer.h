@@ -171,7 +171,12 @@ int dp_plan_profile(dp_plan* plan, int stride);
  * With chunking on, profile slots 0..3 time the launches of ONE chunk.  0 on error. */
 int64_t dp_plan_gemm_rows(const dp_plan* plan, int64_t n_chains);
 int dp_plan_profile_read(dp_plan* plan, double ms_sum[8], int count[8]);
-/* The clock the chip held under the dominant kernel: every profiled evaluation's mlp.2 launch (ping-pong kernel) has its
+/* Name of the GEMM kernel that profile slot `layer` (0 proj, 1 mlp.0 or the folded proj+mlp.0, 2 mlp.2, 3 mlp.4, 4 mlp.6)
+ * runs on under the current dp_tune settings: "k_gemm_bf16_w4", "k_gemm_bf16_pp", "k_gemm_bf16_ws", "k_gemm_bf16<..>",
+ * "k_gemm_f32", or "" for a slot that launches nothing (slot 0 with "fold_proj").  The library's own dispatch predicate,
+ * so that a benchmark labels its roofline with the kernel that ran.  No counterpart in the reference. */
+const char* dp_plan_gemm_kernel(const dp_plan* plan, int layer);
+/* The clock the chip held under the dominant kernel: every profiled evaluation's mlp.2 launch (on the four-wave or the ping-pong kernel, whichever runs that layer) has its
  * workgroup 0 read the shader clock (s_memtime) and the 100 MHz wall clock (s_memrealtime) at its start and end -- two
  * scalar reads per LAUNCH, none in unprofiled launches.  Returns the sums over the samples: shader cycles and wall
  * microseconds of that workgroup's lifetime (clock = cycles / us MHz; FLOP per cycle = launch FLOPs / cycles).  No

@@ -60,7 +60,9 @@ def _adult_table(n, seed=41):
     z = rng.standard_normal((n, 2)).astype(np.float32)
     num = (z @ rng.standard_normal((2, 6)).astype(np.float32) + 0.1 * rng.standard_normal((n, 6))).astype(np.float32)
     score = z @ rng.standard_normal((2, len(n_cat))).astype(np.float32)
-    cat = np.stack([np.clip(((score[:, j] + 2.5) / 5.0 * k).astype(np.int64), 0, k - 1) for j, k in enumerate(n_cat)], axis=1)
+    # equal-frequency buckets of the score: every category occurs, so no binary-digit column is constant (a constant column
+    # has std 0 and the reference's normalisation, main.py:58, divides by it)
+    cat = np.stack([np.minimum(np.argsort(np.argsort(score[:, j])) * k // n, k - 1) for j, k in enumerate(n_cat)], axis=1)
     X, bins = layout.encode_table(num, cat, n_cat)
     mask0 = rng.random((n, 6 + len(n_cat))) < 0.3
     return X, layout.extend_mask(mask0, 6, bins), mask0, cat, bins, n_cat

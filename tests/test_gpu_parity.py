@@ -878,7 +878,7 @@ def test_gemm_kernel_choice_does_not_change_results(d):
 
 def test_profile_clock_samples_the_dominant_kernel():
     """dp_plan_profile_clock (bench.py's in-kernel clock reading): profiled evaluations of a plan whose mlp.2 runs on the
-    ping-pong kernel yield samples with a shader clock in the chip's range and cycles consistent with the event timing."""
+    four-wave kernel (the default; the ping-pong kernel has the same hook) yield samples with a shader clock in the chip's range and cycles consistent with the event timing."""
     d, hid, S, R = 256, 1024, 3, 2
     p = _plan(synth.make_weights(d, hid, 1, 1.0), S, R, "bf16")
     X, mask = synth.make_table(8192, d, seed=3)
