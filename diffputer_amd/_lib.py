@@ -43,6 +43,8 @@ SIGNATURES = {
     "dp_linear": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "dp_masked_mean_std": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "dp_masked_errors": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "dp_mstep_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "dp_mstep_fwd_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp, _sz, _vp]),
     "dp_noise_field": (_i, [_vp, _i64, _i, _u64, _u64, _i, _u32, _i, _vp]),
 }
 

@@ -134,10 +134,13 @@ static const DeviceState* device_state_bf16() {
     return ds;
 }
 
+// `slices` > 1: a batched launch (split-K products of the M-step): slice s multiplies A + s * a_bs by W + s * w_bs (byte
+// strides; rows `ld` elements apart) into out + s * o_bs
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
-                          int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr, unsigned long long* clk = nullptr) {
+                          int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr, unsigned long long* clk = nullptr,
+                          int slices = 1, int ld = 0, long long a_bs = 0, long long w_bs = 0, long long o_bs = 0) {
     const int nbn = N / PP_BN;
-    const int64_t nwg64 = (M / PP_BM) * nbn;
+    const int64_t nwg64 = (M / PP_BM) * nbn * slices;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
     const int nwg = (int)nwg64;
     const DeviceState* ds = device_state_bf16();
@@ -145,8 +148,9 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     const int num_cus = ds->num_cus;
     MidStep ms = mid ? *mid : MidStep{};
     ms.clk = clk;
+    const PpBatch pb = {ld ? ld : K, nwg / slices, a_bs, w_bs, o_bs};
 #define DP_GO(ACT, EP)                                                                                              \
-    hipLaunchKernelGGL((k_gemm_bf16_pp<ACT, EP>), dim3(std::min(nwg, num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms)
+    hipLaunchKernelGGL((k_gemm_bf16_pp<ACT, EP>), dim3(std::min(nwg, num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms, pb)
     if (mid) {
         if (act || N != 256) return fail(DP_EINVAL, "the fused mid-step epilogue needs N = 256 and no activation");
         DP_GO(false, EPI_MID);
@@ -328,6 +332,10 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
     DP_LAUNCH_CHECK("k_gemm_f32");
     return DP_OK;
 }
+
+}  // namespace dp
+#include "dp_mstep_host.h"
+namespace dp {
 
 // ---- workspace -------------------------------------------------------------------------------------------------
 struct Workspace {
@@ -1018,6 +1026,24 @@ int dp_masked_errors(const float* pred, const float* truth, const uint8_t* mask,
     hipLaunchKernelGGL(k_masked_errors, dim3(grid_for(n_rows * d)), dim3(256), 0, st, pred, truth, mask, n_rows * d, d, ld_mask, num_num, sums);
     DP_LAUNCH_CHECK("k_masked_errors");
     return DP_OK;
+}
+
+size_t dp_mstep_workspace_bytes(int d_in, int hid, int64_t batch) {
+    if (d_in < 1 || d_in > 4096 || hid < 64 || hid % 64 || batch < 1 || batch > (1 << 20)) { fail(DP_EINVAL, "dp_mstep_workspace_bytes: bad shape"); return 0; }
+    return ms_carve(ms_dims(d_in, hid, batch), nullptr).bytes;
+}
+
+int dp_mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const float* z_sigma, const float* z_noise,
+                     const float* const w[7], const float* const b[7], float* const gw[7], float* const gb[7], float* loss,
+                     float* percell, void* workspace, size_t workspace_bytes, void* stream) {
+    if (d_in < 1 || d_in > 4096) return fail(DP_EINVAL, "d_in=%d out of range [1, 4096]", d_in);
+    if (hid < 64 || hid % 64) return fail(DP_EINVAL, "hid=%d must be a positive multiple of 64", hid);
+    if (batch < 1 || batch > (1 << 20)) return fail(DP_EINVAL, "batch=%lld out of range [1, 2^20]", (long long)batch);
+    if (!x || !z_sigma || !z_noise || !w || !b || !gw || !gb || !loss || !workspace) return fail(DP_EINVAL, "NULL argument");
+    for (int i = 0; i < 7; ++i)
+        if (!w[i] || !b[i] || !gw[i] || !gb[i]) return fail(DP_EINVAL, "parameter / gradient pointer %d is NULL", i);
+    if (((uintptr_t)workspace & 255) != 0) return fail(DP_EINVAL, "workspace must be 256-byte aligned");
+    return mstep_fwd_bwd(d_in, hid, batch, x, z_sigma, z_noise, w, b, gw, gb, loss, percell, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dp_noise_field(float* out, int64_t n_rows, int d_in, uint64_t seed, uint64_t row_offset, int trial, uint32_t block, int comp,

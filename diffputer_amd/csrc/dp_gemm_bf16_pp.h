@@ -69,10 +69,18 @@ __device__ unsigned long long* g_pp_stamp_buf = nullptr;        // [gridDim][16 
 //             issued after it, not before.
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_MID = 2 };
 
+// Batched launches (the M-step's split-K products, dp_mstep_host.h): tile index = slice * tps + tile within the slice; slice s
+// reads A + s * a_bs and W + s * w_bs (bytes) with row stride `ld` elements (a slice is a column range of longer rows) and
+// writes out + s * o_bs.  Plain launches: ld = K, tps = nwg, strides 0.
+struct PpBatch {
+    int ld, tps;
+    long long a_bs, w_bs, o_bs;
+};
+
 template <bool ACT, int EPI>
 __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
-                                                              int ldo, int K, int nbn, int nwg, MidStep ms) {
+                                                              int ldo, int K, int nbn, int nwg, MidStep ms, PpBatch pb) {
     constexpr bool OUT_F32 = EPI == EPI_F32;
     constexpr bool PREFETCH = EPI != EPI_MID;                   // next tile's prologue DMA ahead of this tile's epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,10 +106,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     // Source addresses are a wave-uniform base (SGPRs) + a 32-bit per-lane byte offset, so the eight DMA streams share
     // two address VGPRs.
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const unsigned a_voff = (unsigned)(((wave * 8 + srow) * K + schunk * 8) * 2);                     // h = 0, piece `wave`
-    const unsigned w_voff = (unsigned)((((wave >> 2) * 64 + (wave & 3) * 8 + srow) * K + schunk * 8) * 2);
-    const size_t a_p2 = (size_t)256 * K, a_h = (size_t)128 * K;  // bytes: second piece = other wave row (+128 rows); half 1 = +64 rows
-    const size_t w_p2 = (size_t)256 * K, w_h = (size_t)64 * K;   // bytes: second piece = wave col + 2 (+128 cols); half 1 = +32 cols
+    const int ld = pb.ld;                                        // row stride of both operands in elements (= K unless batched)
+    const unsigned a_voff = (unsigned)(((wave * 8 + srow) * ld + schunk * 8) * 2);                    // h = 0, piece `wave`
+    const unsigned w_voff = (unsigned)((((wave >> 2) * 64 + (wave & 3) * 8 + srow) * ld + schunk * 8) * 2);
+    const size_t a_p2 = (size_t)256 * ld, a_h = (size_t)128 * ld;  // bytes: second piece = other wave row (+128 rows); half 1 = +64 rows
+    const size_t w_p2 = (size_t)256 * ld, w_h = (size_t)64 * ld;   // bytes: second piece = wave col + 2 (+128 cols); half 1 = +32 cols
     char* const lds_piece = smem + wave * 1024;
     const char *a_base, *w_base;                                 // wave-uniform: first byte of the tile's A rows / W rows
 
@@ -135,9 +144,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
         glds16(src + w_p2 + vo, dst + 8192);
     };
     // prologue DMA of a tile: half-tiles in staging order A0(0) B0(0) B1(0) A1(0) A0(1) B0(1)
-    auto prologue = [&](int m0, int n0) {
-        a_base = (const char*)A + (size_t)m0 * K * 2;
-        w_base = (const char*)W + (size_t)n0 * K * 2;
+    auto prologue = [&](int m0, int n0, int sl) {
+        a_base = (const char*)A + (size_t)sl * pb.a_bs + (size_t)m0 * ld * 2;
+        w_base = (const char*)W + (size_t)sl * pb.w_bs + (size_t)n0 * ld * 2;
         stage_b(0, 1); stage_a(0, 0); stage_b(0, 0); stage_a(0, 1); stage_b(1, 1); stage_a(1, 0); stage_b(1, 0);
     };
 
@@ -238,11 +247,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
 #define PP_WAIT_T1(c) DP_VMCNT(0)                                                                                /* tile nk-1 */
 
     // tile coordinates live in SGPRs (integer division runs on the VALU: read the result back)
-    auto tile_m0 = [&](int tile) { return __builtin_amdgcn_readfirstlane((tile / nbn) * PP_BM); };
-    auto tile_n0 = [&](int tile) { return __builtin_amdgcn_readfirstlane((tile % nbn) * PP_BN); };
+    auto tile_sl = [&](int tile) { return __builtin_amdgcn_readfirstlane(tile / pb.tps); };
+    auto tile_m0 = [&](int tile) { return __builtin_amdgcn_readfirstlane(((tile % pb.tps) / nbn) * PP_BM); };
+    auto tile_n0 = [&](int tile) { return __builtin_amdgcn_readfirstlane(((tile % pb.tps) % nbn) * PP_BN); };
     int tile = xcd_remap(blockIdx.x, G);                         // host guarantees G <= nwg
-    int m0 = tile_m0(tile), n0 = tile_n0(tile);
-    prologue(m0, n0);
+    int m0 = tile_m0(tile), n0 = tile_n0(tile), sl = tile_sl(tile);
+    prologue(m0, n0, sl);
     bool first = true;
 
 #ifdef DP_PP_STAMP
@@ -313,13 +323,15 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
             for (int j = 0; j < 2; ++j)
                 asm volatile("" : "+v"(bv[hb][j].x), "+v"(bv[hb][j].y), "+v"(bv[hb][j].z), "+v"(bv[hb][j].w));
         const int om = m0 + wm * 128, on = n0 + wn * 64;
+        char* const out_sl = (char*)out + (size_t)sl * pb.o_bs;   // this tile's slice of the output
 
         tile += G;
         const bool more = tile < nwg;
         if (more) {
             m0 = tile_m0(tile);
             n0 = tile_n0(tile);
-            if (PREFETCH) prologue(m0, n0);
+            sl = tile_sl(tile);
+            if (PREFETCH) prologue(m0, n0, sl);
         }
         // The counted waits of the next tile's K-tile 0 (PP_WAIT_T0, the vmcnt(8 + NST) above) assume the in-order vmcnt
         // queue holds [prologue DMA][NST epilogue stores]: pin that order -- nothing of the epilogue may be scheduled above
@@ -353,9 +365,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
                             }
                     }
                 }
-            if (more) prologue(m0, n0);
+            if (more) prologue(m0, n0, sl);
         } else if (OUT_F32) {
-            float* const orow = (float*)out + (size_t)(om + (elane & 15)) * ldo + on + (elane >> 4) * 4;
+            float* const orow = (float*)out_sl + (size_t)(om + (elane & 15)) * ldo + on + (elane >> 4) * 4;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
             // write address of 8-byte unit u = hb*8 + j*4 + wq of row wr: chunk (u>>1) ^ (wr&7), half u&1
             const unsigned wa = stg + wr * 128 + ((((wq >> 1) ^ (wr & 7))) << 4) + (wq & 1) * 8;
             const unsigned ra = stg + rr * 128 + ((rc ^ rr) << 4);                         // rows rr + 8s: + 1024 s
-            bf16_t* const orow = (bf16_t*)out + (size_t)(om + rr) * ldo + on + rc * 8;
+            bf16_t* const orow = (bf16_t*)out_sl + (size_t)(om + rr) * ldo + on + rc * 8;
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll

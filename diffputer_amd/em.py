@@ -1,7 +1,9 @@
 """The EM loop around the E-step, as a function (counterpart of main.py:74-262; no CLI, no dataset loading).
 
-M-step = PyTorch (BASELINE.json north_star: "PyTorch-ROCm owns tensors and the M-step"): the reference's training loop
-(main.py:92-152) on `model.Model`, data resident on the device.  E-step = `estep.e_step` on the HIP sampler.  Scoring =
+M-step = the reference's training loop (main.py:92-152) on `model.Model`, data resident on the device: PyTorch owns the
+parameters, the draws, Adam and the scheduler (BASELINE.json north_star: "PyTorch-ROCm owns tensors and the M-step"); on a
+CUDA device the loss and gradients of a batch come from the HIP training step (mstep.py), on CPU from
+autograd.  E-step = `estep.e_step` on the HIP sampler.  Scoring =
 `prep.masked_errors` on the device.  Files written are the reference's (formats.py): `<ckpt_dir>/<k>/model.pt`,
 `<ckpt_dir>/iter_<k+1>.npy`.
 """
@@ -17,14 +19,24 @@ from .model import MLPDiffusion, Model
 
 
 def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, batch_size: int = 4096, lr: float = 1e-4,
-           patience: int = 500, generator: torch.Generator | None = None, log=None):
+           patience: int = 500, generator: torch.Generator | None = None, log=None, native: bool | None = None):
     """main.py:92-152: a FRESH MLPDiffusion each EM iteration, Adam(lr 1e-4), ReduceLROnPlateau(0.9, 50), shuffled batches of
     4096, best-epoch-loss checkpoint, early stop after `patience` epochs without improvement.  Returns (model with the best
-    weights loaded, best loss).  `train_data` [N, D] float32 on the training device."""
+    weights loaded, best loss).  `train_data` [N, D] float32 on the training device.
+
+    native: loss and gradients of a batch from the HIP training step (`mstep.NativeTrainStep`, dp_mstep_fwd_bwd: bf16 hi/lo
+    split GEMMs, ~1e-5 of float32 autograd, 1.5x its speed at H = 1024 / batch 4096) instead of PyTorch autograd; the draws,
+    Adam and the scheduler stay PyTorch's.  Default (None): native on a CUDA device, autograd on CPU."""
     dev = train_data.device
     n, d = train_data.shape
     model = Model(denoise_fn=MLPDiffusion(d, hid_dim), hid_dim=d).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0)
+    if native is None:
+        native = dev.type == "cuda" and hid_dim % 64 == 0
+    step = None
+    if native:
+        from .mstep import NativeTrainStep
+        step = NativeTrainStep(model)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0, **({"fused": True} if native else {}))
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.9, patience=50)
     model.train()
     best, best_sd, stale = float("inf"), None, 0
@@ -33,9 +45,12 @@ def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, b
         tot = torch.zeros((), device=dev)
         for b0 in range(0, n, batch_size):
             x = train_data[perm[b0:b0 + batch_size]]
-            loss = model(x).mean()
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
+            if step is not None:
+                loss = step.loss_and_grads(x)              # overwrites every .grad: zero_grad + backward in one call
+            else:
+                loss = model(x).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
             opt.step()
             tot += loss.detach() * x.shape[0]              # accumulated on the device: one host sync per epoch, not per batch
         cur = float(tot) / n
@@ -105,10 +120,11 @@ class EMResult:
 
 def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, max_iter: int = 10, num_trials: int = 20,
            num_steps: int = 50, device="cuda:0", ckpt_dir: str | None = None, max_epochs: int = 10001, dtype: str | None = None,
-           seed: int = 0, num_num: int | None = None, oos_drop_rows=None, log=print) -> EMResult:
+           seed: int = 0, num_num: int | None = None, oos_drop_rows=None, log=print, native_mstep: bool | None = None) -> EMResult:
     """X, X_test: normalised tables ((x - mean)/std/2, main.py:58,61) holding the TRUE values (used for scoring only, like the
     reference); masks True = missing.
     `oos_drop_rows`: rows of the test table left out of its score (news: [6265], dataset.py:194-197).
+    `native_mstep`: see `m_step(native=...)`; None = the HIP training step on a CUDA device, PyTorch autograd on CPU.
 
     Under torch.distributed (every rank calls this with the same tables): the M-step runs on rank 0 only -- the reference
     has ONE trainer and GPU training is not bit-reproducible across ranks -- and its best weights are broadcast, so every
@@ -127,7 +143,7 @@ def run_em(X, mask_train, X_test=None, mask_test=None, *, hid_dim: int = 1024, m
     for it in range(max_iter):
         log(f"EM iteration {it}: M-step on {tuple(train_data.shape)}")
         if rank == 0:
-            model, loss = m_step(train_data, hid_dim, max_epochs=max_epochs, generator=gen, log=log)
+            model, loss = m_step(train_data, hid_dim, max_epochs=max_epochs, generator=gen, log=log, native=native_mstep)
         else:
             model, loss = Model(denoise_fn=MLPDiffusion(X.shape[1], hid_dim), hid_dim=X.shape[1]).to(dev).eval(), 0.0
         if distributed:

@@ -237,6 +237,29 @@ int dp_masked_errors(const float* pred, const float* truth, const uint8_t* mask,
                      int num_num, double* sums, void* stream);
 
 /*
+ * One M-step training step's arithmetic: the EDM loss of a batch and its gradient for the 14 parameter tensors.
+ * Replaces: `loss = model(inputs)` ... `loss.backward()` (main.py:124-131), i.e. Model.forward (model.py:171-181) ->
+ * EDMLoss.__call__ (diffusion_utils.py:200-215) -> Precond.forward with per-row sigma (model.py:148-165) ->
+ * MLPDiffusion.forward (model.py:121-128), and autograd's backward through all of it.  The optimiser step stays the
+ * caller's (torch.optim.Adam, main.py:109,132).
+ *   x        [batch, d_in]  the training rows of this batch (main.py:122)
+ *   z_sigma  [batch]        the standard-normal draw behind sigma = exp(1.2 z - 1.2)   (torch.randn, diffusion_utils.py:202)
+ *   z_noise  [batch, d_in]  the standard-normal draw behind n = z sigma                (torch.randn_like, :208)
+ *   w, b     the 14 parameters, float32, torch.nn.Linear layout, order as dp_plan_set_weights
+ *   gw, gb   receive the gradients (same shapes; overwritten, not accumulated)
+ *   loss     one float32: mean over the batch's cells                                  (model.py:180-181)
+ *   percell  NULL, or [batch, d_in] receiving the per-cell loss                        (diffusion_utils.py:213)
+ * Arithmetic: float32 everywhere except the GEMMs, whose float32 operands are split into bf16 hi + lo and multiplied as
+ * three bf16 MFMA products with float32 accumulation (error per product ~1e-5 relative; diffputer_amd/csrc/dp_mstep.h).
+ * Deterministic: same inputs, same bits (every reduction has a fixed order).  Asynchronous on `stream`; allocates nothing
+ * (workspace >= dp_mstep_workspace_bytes(d_in, hid, batch), 256-byte aligned).
+ */
+size_t dp_mstep_workspace_bytes(int d_in, int hid, int64_t batch);
+int dp_mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const float* z_sigma, const float* z_noise,
+                     const float* const w[7], const float* const b[7], float* const gw[7], float* const gb[7],
+                     float* loss, float* percell, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Fill out[n_rows, d_in] with one of the Gaussian fields dp_impute draws when noise == NULL, for global rows
  * row_offset.. and global trial `trial`: block = inner-iteration index (or 0xFFFFFFFF = before the first iteration),
  * comp = kind: 0 = n_prev of that iteration (diffusion_utils.py:45; for 0xFFFFFFFF the initial x_T draw :25),

@@ -34,7 +34,7 @@ def main() -> int:
                    "int, int, int, int, unsigned long long*);" % act)
     for act, epi, _ in VARIANTS:
         src.append("template __global__ void dp::k_gemm_bf16_pp<%s, %d>(const dp::bf16_t*, const dp::bf16_t*, const float*, void*, "
-                   "int, int, int, int, dp::MidStep);" % (act, epi))
+                   "int, int, int, int, dp::MidStep, dp::PpBatch);" % (act, epi))
     with tempfile.TemporaryDirectory() as d:
         hip, asm = os.path.join(d, "pp.hip"), os.path.join(d, "pp.s")
         open(hip, "w").write("\n".join(src) + "\n")

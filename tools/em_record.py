@@ -25,6 +25,7 @@ ap.add_argument("--iters", type=int, default=2)
 ap.add_argument("--epochs", type=int, default=150)
 ap.add_argument("--trials", type=int, default=20)
 ap.add_argument("--hid", type=int, default=1024)
+ap.add_argument("--mstep", default="native", choices=["native", "autograd"], help="loss + gradients from dp_mstep_fwd_bwd or from PyTorch autograd")
 a = ap.parse_args()
 dev = "cuda:0"
 rng = np.random.default_rng(1994)
@@ -58,15 +59,15 @@ def timed(fn, key):
 em.m_step = timed(orig_m, "m_step_s")
 estep.e_step = timed(orig_e, "e_step_s")
 res = em.run_em(Xn, md, hid_dim=a.hid, max_iter=a.iters, num_trials=a.trials, num_steps=50, device=dev, max_epochs=a.epochs, seed=7,
-                num_num=6, log=lambda *_: None)
+                num_num=6, log=lambda *_: None, native_mstep=a.mstep == "native")
 zero_mae, zero_rmse = prep.masked_errors(torch.zeros_like(Xn), Xn * 2, md, num_num=6)
 rec = res.imputed / 2 * 2 * std + mean
 got = layout.decode_bits(rec[:, 6:].cpu().numpy(), bins)
 miss = mask0[:, 6:]
 print(json.dumps({
     "workload": f"BASELINE configs[1]: adult-shaped mixed table {N} x {X.shape[1]} (6 numeric + 28 binary digits, synthetic), EM loop: "
-                f"{a.iters} iterations x (M-step {a.epochs} epochs, batch 4096, PyTorch float32; E-step S=50 x R=20 x Heun, T={a.trials}, bf16 HIP)",
-    "hid": a.hid, "m_step_s": times["m_step_s"], "e_step_s": times["e_step_s"],
+                f"{a.iters} iterations x (M-step {a.epochs} epochs, batch 4096, " + ("HIP training step (bf16 hi/lo split GEMMs) + PyTorch Adam" if a.mstep == "native" else "PyTorch float32 autograd") + f"; E-step S=50 x R=20 x Heun, T={a.trials}, bf16 HIP)",
+    "hid": a.hid, "mstep": a.mstep, "m_step_s": times["m_step_s"], "e_step_s": times["e_step_s"],
     "e_step_rows_per_s": [N / t for t in times["e_step_s"]],
     "mae_in": res.mae_in, "rmse_in": res.rmse_in, "zero_fill_mae_rmse": [zero_mae, zero_rmse], "train_loss": res.train_loss,
     "categorical_accuracy_on_masked_cells": float((got[miss] == cat[miss]).mean()),

@@ -91,5 +91,32 @@ def graphed():
 
 
 print(f"d={a.d} hid={a.hid} batch={a.batch}: graph {timeit(graphed):.3f} ms/step (loss {float(static_loss):.4f})")
+# ---- the native training step (dp_mstep_fwd_bwd: bf16 hi/lo split, three MFMA products per float32 product) + PyTorch's Adam ----
+from diffputer_amd.mstep import NativeTrainStep  # noqa: E402
+
+for fused in (False, True):
+    model, _ = build(False)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, fused=fused)
+    step = NativeTrainStep(model)
+
+    def native():
+        step.loss_and_grads(xb)
+        opt.step()
+
+    print(f"d={a.d} hid={a.hid} batch={a.batch}: native fwd+bwd + Adam(fused={fused}) {timeit(native):.3f} ms/step")
+
+model, _ = build(False)
+step = NativeTrainStep(model)
+print(f"d={a.d} hid={a.hid} batch={a.batch}: native fwd+bwd only {timeit(lambda: step.loss_and_grads(xb)):.3f} ms/step")
+model, _ = build(False)
+
+
+def eager_nograd_step():
+    loss = model(xb).mean()
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+
+
+print(f"d={a.d} hid={a.hid} batch={a.batch}: eager fwd+bwd only {timeit(eager_nograd_step):.3f} ms/step")
 flops = 3 * a.batch * (4.0 * a.d * a.hid + 16.0 * a.hid * a.hid + 4.0 * a.hid * a.hid)
 print(f"GEMM work per step (fwd + 2x bwd, incl. the per-row time embedding) = {flops/1e12:.3f} TFLOP")
