@@ -78,6 +78,50 @@ def cpu_baseline(d, hid, S, R, T, rows, budget_note):
             "row_trials_per_s": row_trials_per_s}
 
 
+def mstep_line(d, hid, dev, batch=4096, steps=40):
+    """SURVEY.md §8 f1 beside the E-step: one M-step training step (main.py:119-133: loss, backward, Adam) at the reference's
+    batch size, on the HIP training step (dp_mstep_fwd_bwd + PyTorch's fused Adam) and on PyTorch eager autograd."""
+    from diffputer_amd.model import MLPDiffusion, Model
+    from diffputer_amd.mstep import NativeTrainStep
+    torch.manual_seed(0)
+    x = torch.randn(batch, d, device=dev) * 0.5
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    model = Model(denoise_fn=MLPDiffusion(d, hid), hid_dim=d).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0, fused=True)
+    step = NativeTrainStep(model)
+
+    def native():
+        step.loss_and_grads(x)
+        opt.step()
+
+    native_ms = timed(native)
+    model = Model(denoise_fn=MLPDiffusion(d, hid), hid_dim=d).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0)
+
+    def eager():
+        loss = model(x)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    eager_ms = timed(eager)
+    flops = 3 * batch * (4.0 * d * hid + 16.0 * hid * hid + 4.0 * hid * hid)      # fwd + 2 x bwd, incl. the per-row time embedding
+    return {"batch": batch, "native_ms_per_step": native_ms, "pytorch_eager_ms_per_step": eager_ms, "speedup": eager_ms / native_ms,
+            "float32_equivalent_tflops": {"native": flops / native_ms / 1e9, "pytorch_eager": flops / eager_ms / 1e9},
+            "note": "native = dp_mstep_fwd_bwd (float32 operands split into bf16 hi + lo, three bf16 MFMA products per float32 product) "
+                    "+ torch.optim.Adam(fused=True); gradients within 1e-4 of the reference's float32 autograd (tests/test_gpu_mstep.py)"}
+
+
 def csrc_sha() -> str:
     """sha256 over the kernel sources: PMC_TRAFFIC.json is stamped with it (tools/pmc_summary.py --stamp) so counters
     measured on other kernels are never reported as this build's."""
@@ -174,6 +218,7 @@ def main():
     ap.add_argument("--max-chains", type=int, default=1 << 16)
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-mstep", action="store_true", help="skip the M-step training-step timing (SURVEY.md section 8 f1) beside the E-step line")
     ap.add_argument("--no-fold", action="store_true", help="run proj and mlp.0 as two GEMMs (dp_tune fold_proj=0)")
     ap.add_argument("--tune", action="append", default=[], help="dp_tune key=value (A/B runs), e.g. --tune ws_gemm=0")
     ap.add_argument("--m-chunk", type=int, default=None, help="rows per wide-layer GEMM launch (dp_tune m_chunk; 0 = whole batch)")
@@ -370,6 +415,8 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    if rank == 0 and a.gpus == 1 and not a.standin and not a.no_mstep and hid % 64 == 0:
+        result["mstep"] = mstep_line(d, hid, dev)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -892,3 +892,30 @@ def test_profile_clock_samples_the_dominant_kernel():
     mhz = cyc / us
     assert 800.0 < mhz < 2600.0, mhz                                     # MI355X: up to 2.4 GHz, well below it under this kernel
     assert 0.5 < (us / n) / (ms[2] / cnt[2] * 1e3) < 1.1                 # workgroup 0's lifetime vs the launch's event time
+
+
+def test_gemm_kernel_query_follows_the_dispatch():
+    """dp_plan_gemm_kernel (bench.py must label its roofline with the kernel that ran): the library's own dispatch
+    predicate per profile slot, under the default settings and under the A/B knobs."""
+    from diffputer_amd import _lib
+    lib = _lib.load()
+    p = _plan(synth.make_weights(256, 1024, 1, 1.0), 3, 2, "bf16")
+    q = _plan(synth.make_weights(34, 1024, 1, 1.0), 3, 2, "bf16")
+    f = _plan(synth.make_weights(34, 64, 1, 1.0), 3, 2, "f32")
+    try:
+        assert [p.gemm_kernel(i) for i in range(5)] == ["", "k_gemm_bf16_pp", "k_gemm_bf16_w4", "k_gemm_bf16_w4", "k_gemm_bf16_pp"]
+        assert [q.gemm_kernel(i) for i in range(5)] == ["", "k_gemm_bf16_ws", "k_gemm_bf16_w4", "k_gemm_bf16_w4", "k_gemm_bf16<128,64>"]
+        assert [f.gemm_kernel(i) for i in range(5)] == ["k_gemm_f32"] * 5
+        _lib.check(lib.dp_tune(b"gemm_variant", 2), "dp_tune")
+        assert [p.gemm_kernel(i) for i in (1, 2, 3)] == ["k_gemm_bf16_pp"] * 3
+        _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
+        _lib.check(lib.dp_tune(b"w4_min_k", 256), "dp_tune")
+        assert p.gemm_kernel(1) == "k_gemm_bf16_w4"
+        _lib.check(lib.dp_tune(b"fold_proj", 0), "dp_tune")
+        assert q.gemm_kernel(0) == "k_gemm_bf16_ws" and q.gemm_kernel(1) == "k_gemm_bf16_w4"
+    finally:
+        _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
+        _lib.check(lib.dp_tune(b"w4_min_k", 1024), "dp_tune")
+        _lib.check(lib.dp_tune(b"fold_proj", 1), "dp_tune")
+        for x in (p, q, f):
+            x.close()

@@ -9,3 +9,5 @@ mkdir -p tools/diag
     -o tools/diag/libdp_ws_stamp.so diffputer_amd/csrc/diffputer_hip.hip
 # issue probe: does VALU work of one wave run under another wave's MFMAs on the same SIMD?
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/diag/issue_probe tools/issue_probe.hip
+# SiLU formulations for the GEMM epilogues: cycles per value and accuracy
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/diag/silu_probe tools/silu_probe.hip
