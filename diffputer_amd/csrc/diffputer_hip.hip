@@ -138,7 +138,7 @@ static const DeviceState* device_state_bf16() {
 // strides; rows `ld` elements apart) into out + s * o_bs
 static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int K,
                           int act, int out_f32, hipStream_t st, const MidStep* mid = nullptr, unsigned long long* clk = nullptr,
-                          int slices = 1, int ld = 0, long long a_bs = 0, long long w_bs = 0, long long o_bs = 0) {
+                          int slices = 1, int ld = 0, long long a_bs = 0, long long w_bs = 0, long long o_bs = 0, bool x3 = false) {
     const int nbn = N / PP_BN;
     const int64_t nwg64 = (M / PP_BM) * nbn * slices;
     if (nwg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM grid too large");
@@ -151,7 +151,10 @@ static int launch_bf16_pp(const bf16_t* A, const bf16_t* W, const float* bias, v
     const PpBatch pb = {ld ? ld : K, nwg / slices, a_bs, w_bs, o_bs};
 #define DP_GO(ACT, EP)                                                                                              \
     hipLaunchKernelGGL((k_gemm_bf16_pp<ACT, EP>), dim3(std::min(nwg, num_cus)), dim3(PP_THREADS), PP_LDS_TOTAL, st, A, W, bias, out, ldo, K, nbn, nwg, ms, pb)
-    if (mid) {
+    if (x3) {
+        if (act || !out_f32 || mid || K % 768) return fail(DP_EINVAL, "the three-product GEMM needs float32 output, no activation and K %% 768 == 0");
+        DP_GO(false, EPI_F32X3);
+    } else if (mid) {
         if (act || N != 256) return fail(DP_EINVAL, "the fused mid-step epilogue needs N = 256 and no activation");
         DP_GO(false, EPI_MID);
     } else if (act && !out_f32) DP_GO(true, EPI_BF16);
@@ -255,6 +258,7 @@ static int ensure_device_ready(int dev) {
     DP_ATTR((k_gemm_bf16_pp<true, EPI_F32>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_pp<false, EPI_F32>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_pp<false, EPI_MID>), PP_LDS_TOTAL);
+    DP_ATTR((k_gemm_bf16_pp<false, EPI_F32X3>), PP_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_w4<true>), W4_LDS_TOTAL);
     DP_ATTR((k_gemm_bf16_w4<false>), W4_LDS_TOTAL);
 #define DP_ATTR4(BM, BN, WM, WN)                                                                  \

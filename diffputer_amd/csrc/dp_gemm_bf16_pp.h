@@ -67,7 +67,10 @@ __device__ unsigned long long* g_pp_stamp_buf = nullptr;        // [gridDim][16 
 //             iteration; apply k_step_mid's arithmetic in place (reads x_hat, writes d_cur and the next evaluation's
 //             input u) instead of storing F.  Its epilogue waits on ordinary loads, so the next tile's prologue is
 //             issued after it, not before.
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_MID = 2 };
+//   EPI_F32X3 as EPI_F32, for the M-step's three-product GEMMs (dp_mstep.h): the operands hold, per block of 256 logical
+//             columns, [hi (256) | lo (256)]; the K loop runs over THREE 256-wide segments per block and maps them to the
+//             stored parts -- A operand (hi, lo, hi), W operand (hi, hi, lo) -- so hi and lo are stored once.
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_MID = 2, EPI_F32X3 = 3 };
 
 // Batched launches (the M-step's split-K products, dp_mstep_host.h): tile index = slice * tps + tile within the slice; slice s
 // reads A + s * a_bs and W + s * w_bs (bytes) with row stride `ld` elements (a slice is a column range of longer rows) and
@@ -81,7 +84,8 @@ template <bool ACT, int EPI>
 __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int ldo, int K, int nbn, int nwg, MidStep ms, PpBatch pb) {
-    constexpr bool OUT_F32 = EPI == EPI_F32;
+    constexpr bool OUT_F32 = EPI == EPI_F32 || EPI == EPI_F32X3;
+    constexpr bool X3 = EPI == EPI_F32X3;
     constexpr bool PREFETCH = EPI != EPI_MID;                   // next tile's prologue DMA ahead of this tile's epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // vector-memory instructions one wave's epilogue issues (they sit between the next tile's prologue DMA and its
@@ -114,6 +118,14 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
     char* const lds_piece = smem + wave * 1024;
     const char *a_base, *w_base;                                 // wave-uniform: first byte of the tile's A rows / W rows
 
+    // byte offset of K-tile kt within a row.  X3: K-tile kt = segment (kt % 12) / 4 of block kt / 12; the segment's part
+    // (0 = hi, 1 = lo) is `part_a` / `part_w` of it; a block is 512 stored columns.
+    auto koff = [&](int kt, bool is_w) -> size_t {
+        if (!X3) return (size_t)kt * (PP_BK * 2);
+        const int f = kt / 12, r = kt - f * 12, seg = r >> 2, q = r & 3;
+        const int part = is_w ? (seg == 2) : (seg == 1);
+        return (size_t)(f * 512 + part * 256 + q * 64) * 2;
+    };
     // slot of (buffer b, operand o, half h) = ((b * 2 + o) * 2 + h) * 16 KiB
     auto stage_a = [&](int kt, int h) {
         char* dst = lds_piece + ((kt & 1) * 4 + h) * PP_HALF;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
 #ifdef PP_DIAG_NOSTAGE
         if (kt >= 2) return;                                     // diagnostic: no DMA after the prologue (the waits pass at once)
 #endif
-        const char* src = a_base + h * a_h + (size_t)kt * (PP_BK * 2);
+        const char* src = a_base + h * a_h + koff(kt, false);
         unsigned vo = a_voff;
         asm volatile("" : "+v"(vo));                             // keep base + offset un-hoisted: selects the saddr + voffset form
         glds16(src + vo, dst);
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_gemm_bf16_pp(const bf16_t* __res
 #ifdef PP_DIAG_NOSTAGE
         if (kt >= 2) return;
 #endif
-        const char* src = w_base + h * w_h + (size_t)kt * (PP_BK * 2);
+        const char* src = w_base + h * w_h + koff(kt, true);
         unsigned vo = w_voff;
         asm volatile("" : "+v"(vo));
         glds16(src + vo, dst);

@@ -21,9 +21,9 @@
 // with float32 accumulation in the bf16 MFMA: three bf16 products for one float32 one, on a unit whose peak is 16 x the
 // float32 MFMA's.  Relative error per product ~1e-5 (between float32's 6e-8 and TF32's 5e-4); measured against the
 // reference's gradients in tests/test_gpu_mstep.py.  The three products are ONE GEMM over a three times longer K:
-//     A' = [A_hi | A_lo | A_hi],  W' = [W_hi | W_hi | W_lo]          ("A pattern", "W pattern")
-// so the operands are written once, by the kernel that produces them, in this expanded form -- both as stored and
-// transposed (for the dW products) -- and the GEMM kernels run unchanged (float32 output, no activation).
+//     A' = [A_hi | A_lo | A_hi],  W' = [W_hi | W_hi | W_lo]          (per block of 256 columns)
+// Operands are written once, by the kernel that produces them, as [hi | lo] blocks -- both as stored and transposed (for the
+// dW products) -- and the E-step's ping-pong GEMM maps its K-tiles to the parts (EPI_F32X3: float32 output, no activation).
 // Everything between two GEMMs (bias, SiLU and its derivative, the loss, the split, the transposes, the column sums that
 // are the bias gradients) is ONE tile kernel, k_ms_emit<OP>.
 #pragma once
@@ -32,23 +32,21 @@
 namespace dp {
 
 // An expanded bf16 operand: logical matrix [rows][cols] (cols = the consuming GEMM's reduction dimension, a multiple of
-// 256), stored as [rows][3 * cols] in blocks of 256 columns: block f of a row = [part 0 | part 1 | part 2] of columns
-// 256 f .. 256 f + 255, i.e. part j of element (r, c) at r * 3 cols + (c / 256) * 768 + j * 256 + c % 256.
-// pat 0 = A pattern (hi, lo, hi), 1 = W pattern (hi, hi, lo).  Any column range of whole blocks is itself a valid expanded
-// operand with row stride 3 * cols: that is what a split-K slice of a product reads.  p == nullptr: not wanted.
+// 256), stored as [rows][2 * cols] in blocks of 256 columns: block f of a row = [hi (256) | lo (256)] of columns
+// 256 f .. 256 f + 255, i.e. element (r, c) has hi at r * 2 cols + (c / 256) * 512 + c % 256 and lo 256 further.
+// The GEMM (k_gemm_bf16_pp<false, EPI_F32X3>) walks THREE 256-wide segments per block and maps them to the parts: as its A
+// operand (hi, lo, hi), as its W operand (hi, hi, lo).  Any range of whole blocks is itself a valid operand with row stride
+// 2 * cols: that is what a split-K slice of a product reads.  p == nullptr: not wanted.
 struct MsExp {
     bf16_t* p;
-    int rows, cols, pat;
+    int rows, cols;
 };
-// elements (r, c) and (r, c + 1), c even: three 4-byte stores
+// elements (r, c) and (r, c + 1), c even: two 4-byte stores
 __device__ __forceinline__ void ms_exp_store2(const MsExp& e, int r, int c, float v0, float v1) {
     const bf16_t h0 = f2bf(v0), h1 = f2bf(v1);
-    const uint32_t hi = (uint32_t)h0 | ((uint32_t)h1 << 16);
-    const uint32_t lo = pack_bf16x2(v0 - bf2f(h0), v1 - bf2f(h1));
-    uint32_t* q = (uint32_t*)(e.p + (size_t)r * 3 * e.cols + (c >> 8) * 768 + (c & 255));
-    q[0] = hi;
-    q[128] = e.pat ? hi : lo;
-    q[256] = e.pat ? lo : hi;
+    uint32_t* q = (uint32_t*)(e.p + (size_t)r * 2 * e.cols + (c >> 8) * 512 + (c & 255));
+    q[0] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    q[128] = pack_bf16x2(v0 - bf2f(h0), v1 - bf2f(h1));
 }
 
 __device__ __forceinline__ float ms_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }

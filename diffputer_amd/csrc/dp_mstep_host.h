@@ -43,7 +43,7 @@ static MsWork ms_carve(const MsDims& d, void* base) {
     MsWork w;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += round_up<size_t>(n, 256); return base ? (void*)((char*)base + o) : (void*)nullptr; };
-    auto expd = [&](int rows, int cols) { return (bf16_t*)take((size_t)rows * cols * 3 * sizeof(bf16_t)); };
+    auto expd = [&](int rows, int cols) { return (bf16_t*)take((size_t)rows * cols * 2 * sizeof(bf16_t)); };
     const int maxf = std::max(d.H2p, d.Dp);
     w.rc = (MsRow*)take((size_t)d.Bp * sizeof(MsRow));
     w.noisy = (float*)take((size_t)d.Bp * d.Dp * 4);
@@ -93,14 +93,14 @@ static int ms_split(int tiles, int K) {
     return S;
 }
 
-// gout[s][M][N] (float32) = partial products of A'[M][3K] W'[N][3K]^T over S column slices: ONE batched launch of the
-// ping-pong kernel.  Returns S through *S_out; the consumer sums the partials in slice order.
+// gout[s][M][N] (float32) = partial products of A[M][K] W[N][K]^T (each as three bf16 products) over S column slices: ONE
+// batched launch of the ping-pong kernel.  Returns S through *S_out; the consumer sums the partials in slice order.
 static int ms_gemm(const bf16_t* A, const bf16_t* W, float* out, const float* zero_bias, int M, int N, int K, hipStream_t st, int* S_out) {
     const int S = ms_split((M / 256) * (N / 256), K);
     *S_out = S;
-    const int Ks = 3 * K / S;                                    // expanded columns per slice
-    return launch_bf16_pp(A, W, zero_bias, out, N, M, N, Ks, 0, 1, st, nullptr, nullptr, S, 3 * K, (long long)Ks * 2, (long long)Ks * 2,
-                          (long long)M * N * 4);
+    const int Ks = K / S;                                        // logical columns per slice: 3 Ks of K loop over 2 Ks stored columns
+    return launch_bf16_pp(A, W, zero_bias, out, N, M, N, 3 * Ks, 0, 1, st, nullptr, nullptr, S, 2 * K, (long long)Ks * 4, (long long)Ks * 4,
+                          (long long)M * N * 4, true);
 }
 
 static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const float* z_sigma, const float* z_noise,
@@ -122,21 +122,21 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
     for (int l = 0; l < 7; ++l) {
         MsEmit e = blank();
         e.src = w[l]; e.ld_src = L[l].K; e.m_valid = L[l].N; e.n_valid = L[l].K;
-        e.outN = {k.WN[l], L[l].Np, L[l].Kp, 1};
-        if (l != 0 && l != 5) e.outT = {k.WT[l], L[l].Kp, L[l].Np, 1};           // proj and time_embed.0 have no input gradient
+        e.outN = {k.WN[l], L[l].Np, L[l].Kp};
+        if (l != 0 && l != 5) e.outT = {k.WT[l], L[l].Kp, L[l].Np};           // proj and time_embed.0 have no input gradient
         if ((rc = ms_emit<MS_W>(e, L[l].Np, L[l].Kp, st))) return rc;
     }
     {
         MsEmit e = blank();
         e.src = x; e.x = z_noise; e.rc = k.rc; e.m_valid = d.B; e.n_valid = d.D; e.d_valid = d.D;
         e.f32_out = k.noisy; e.ld_f32 = d.Dp;
-        e.outN = {k.uN, d.Bp, d.Dp, 0}; e.outT = {k.uT, d.Dp, d.Bp, 1};
+        e.outN = {k.uN, d.Bp, d.Dp}; e.outT = {k.uT, d.Dp, d.Bp};
         if ((rc = ms_emit<MS_U>(e, d.Bp, d.Dp, st))) return rc;
     }
     {
         MsEmit e = blank();
         e.rc = k.rc; e.m_valid = d.Bp; e.n_valid = d.H;
-        e.outN = {k.peN, d.Bp, d.Hp, 0}; e.outT = {k.peT, d.Hp, d.Bp, 1};
+        e.outN = {k.peN, d.Bp, d.Hp}; e.outT = {k.peT, d.Hp, d.Bp};
         if ((rc = ms_emit<MS_PE>(e, d.Bp, d.Hp, st))) return rc;
     }
     // forward layer: gout = A W^T, then bias (+ addend), SiLU, split
@@ -148,8 +148,8 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
         e.S = S; e.src_stride = (size_t)d.Bp * L[l].Np;
         e.src = k.gout; e.ld_src = L[l].Np; e.bias = b[l]; e.m_valid = d.Bp; e.n_valid = L[l].N;
         e.addend = addend; e.ld_add = L[l].Np; e.pre_out = pre; e.ld_pre = L[l].Np; e.f32_out = f32_out; e.ld_f32 = L[l].Np;
-        if (outN) e.outN = {outN, d.Bp, L[l].Np, 0};
-        if (outT) e.outT = {outT, L[l].Np, d.Bp, 1};
+        if (outN) e.outN = {outN, d.Bp, L[l].Np};
+        if (outT) e.outT = {outT, L[l].Np, d.Bp};
         return act ? ms_emit<MS_FWD_ACT>(e, d.Bp, L[l].Np, st) : ms_emit<MS_FWD_LIN>(e, d.Bp, L[l].Np, st);
     };
     if ((rc = fwd(5, k.peN, true, k.pre[0], nullptr, nullptr, k.t1N, k.t1T))) return rc;          // time_embed.0 + SiLU
@@ -168,7 +168,7 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
         e.src = k.gout; e.ld_src = d.Dp; e.bias = b[4]; e.rc = k.rc; e.x = x; e.noisy_in = k.noisy; e.ld_noisy = d.Dp;
         e.m_valid = d.B; e.n_valid = d.D; e.d_valid = d.D; e.scale = (float)(2.0 / ((double)d.B * d.D));
         e.percell = percell; e.losspart = k.losspart; e.colpart = k.colpart; e.ld_col = maxf;
-        e.outN = {k.dFN, d.Bp, d.Dp, 0}; e.outT = {k.dFT, d.Dp, d.Bp, 0};
+        e.outN = {k.dFN, d.Bp, d.Dp}; e.outT = {k.dFT, d.Dp, d.Bp};
         if ((rc = ms_emit<MS_LOSS>(e, d.Bp, d.Dp, st))) return rc;
         hipLaunchKernelGGL(k_ms_loss, dim3(1), dim3(256), 0, st, (const double*)k.losspart, nlb, 1.0 / ((double)d.B * d.D), loss);
         DP_LAUNCH_CHECK("k_ms_loss");
@@ -200,8 +200,8 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
         e.S = S; e.src_stride = (size_t)d.Bp * L[l].Kp;
         e.src = k.gout; e.ld_src = L[l].Kp; e.m_valid = d.Bp; e.n_valid = L[l].K; e.pre_in = pre; e.ld_pre = L[l].Kp;
         e.colpart = k.colpart; e.ld_col = maxf;
-        if (outN) e.outN = {outN, d.Bp, L[l].Kp, 0};
-        if (outT) e.outT = {outT, L[l].Kp, d.Bp, 0};
+        if (outN) e.outN = {outN, d.Bp, L[l].Kp};
+        if (outT) e.outT = {outT, L[l].Kp, d.Bp};
         return pre ? ms_emit<MS_BWD_ACT>(e, d.Bp, L[l].Kp, st) : ms_emit<MS_BWD_LIN>(e, d.Bp, L[l].Kp, st);
     };
     // ---- backward (what loss.backward() computes, main.py:131) ----

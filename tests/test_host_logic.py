@@ -533,3 +533,21 @@ def test_mixed_table_layout():
     assert np.array_equal(layout.decode_bits(noisy, bins), cat)
     with pytest.raises(ValueError):
         layout.encode_bits(np.array([16]), 4)
+
+
+def test_native_training_step_host_checks():
+    """The M-step's native entry points without a GPU: dp_mstep_workspace_bytes is host arithmetic (it must grow with the
+    batch, be 256-byte granular and refuse shapes the kernels cannot take), and NativeTrainStep refuses a CPU model loudly --
+    there is no CPU fallback behind it (autograd on `model.Model` is the CPU path)."""
+    from diffputer_amd import _lib
+    from diffputer_amd.mstep import NativeTrainStep
+    lib = _lib.load()
+    a = lib.dp_mstep_workspace_bytes(34, 1024, 4096)
+    b = lib.dp_mstep_workspace_bytes(34, 1024, 8192)
+    assert 0 < a < b and a % 256 == 0
+    assert lib.dp_mstep_workspace_bytes(34, 1024, 4095) == a                      # rows are padded to 256
+    assert lib.dp_mstep_workspace_bytes(34, 100, 4096) == 0 and b"bad shape" in lib.dp_last_error()
+    assert lib.dp_mstep_workspace_bytes(0, 1024, 4096) == 0
+    m = dmodel.Model(dmodel.MLPDiffusion(12, 64), hid_dim=12)
+    with pytest.raises(_lib.DiffputerError):
+        NativeTrainStep(m)
