@@ -3,8 +3,8 @@
 
 Tolerance, stated from the arithmetic (dp_mstep.h): GEMM operands are split into bf16 hi + lo and multiplied as three bf16
 products with float32 accumulation -- ~1e-5 relative per product -- so loss, per-cell loss and every one of the 14 gradients
-are held to 1e-4 of their scale (max |reference gradient| of that tensor); float32 autograd on the same device is the
-second checker, at sizes the fixtures do not cover (a batch that is not a multiple of 256, D = 9).
+are held to 1e-4 of their scale (max |reference gradient| of that tensor); the CPU oracle (oracle/diffputer_oracle_mstep.py,
+pinned to the same fixtures at 1e-5) and float32 autograd on the same device are the checkers at sizes the fixtures do not cover (a batch that is not a multiple of 256, D = 9).
 """
 import numpy as np
 import pytest
@@ -122,6 +122,13 @@ def test_against_float32_autograd_on_ragged_shapes(d, hid, B):
     for k in ref:
         scale = float(ref[k].abs().max())
         assert float((got[k] - ref[k]).abs().max()) <= 1e-4 * scale, (k, float((got[k] - ref[k]).abs().max()), scale)
+    # ... and against the CPU oracle (numpy, hand-written backward; pinned to the reference in tests/test_oracle_golden.py)
+    from oracle import diffputer_oracle_mstep as orm
+    sd = synth.make_weights(d, hid, 55, 1.0)
+    o_loss, _, o_grads = orm.loss_and_grads(sd, x.cpu().numpy(), zs.cpu().numpy(), zn.cpu().numpy())
+    assert abs(float(loss) - float(o_loss)) <= 1e-4 * float(o_loss)
+    for k, r in o_grads.items():
+        assert float(np.abs(got[k].cpu().numpy() - r).max()) <= 1e-4 * float(np.abs(r).max()), k
 
 
 def test_training_with_the_native_step_follows_autograd():

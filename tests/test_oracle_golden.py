@@ -209,3 +209,45 @@ def test_reference_written_checkpoint():
     t = orc.sigma_schedule(int(g["S"]))
     for k, ref in enumerate(g["trace"]):
         close(trace[k], ref, atol=1e-5 * max(1.0, float(t[min(k // int(g["R"]), int(g["S"]) - 1)])))
+
+
+def test_mstep_oracle_small_fixture_all_gradients():
+    """oracle/diffputer_oracle_mstep.py (numpy forward + hand-written backward of Model.forward / EDMLoss / Precond /
+    MLPDiffusion with per-row sigma) against the reference's loss, per-cell loss and all 14 gradients
+    (tests/golden/mstep_D12_H64.npz, tools/make_mstep_golden.py)."""
+    from oracle import diffputer_oracle_mstep as orm
+    g = load_golden("mstep_D12_H64")
+    sd = synth.make_weights(int(g["d_in"]), int(g["hid"]), int(g["wseed"]), float(g["gain"]))
+    loss, percell, grads = orm.loss_and_grads(sd, g["x"], g["z_sigma"], g["z_noise"])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    close(percell, g["percell"], atol=1e-5 * float(np.abs(g["percell"]).mean()), rtol=1e-5)
+    for name in orm.LAYERS:
+        for kind in ("weight", "bias"):
+            ref = g[f"grad__{name}.{kind}"]
+            assert float(np.abs(grads[f"{name}.{kind}"] - ref).max()) <= 1e-5 * float(np.abs(ref).max()), (name, kind)
+
+
+def test_mstep_oracle_reference_width_and_batch():
+    """The same at the reference's real width and batch size: H = 1024, D = 34, B = 4096 (tests/golden/mstep_D34_H1024.npz:
+    loss, per-row loss, bias gradients in full, weight gradients as [::37, ::41] samples + Frobenius norms)."""
+    from oracle import diffputer_oracle_mstep as orm
+    g = load_golden("mstep_D34_H1024")
+    d, hid, B = int(g["d_in"]), int(g["hid"]), int(g["B"])
+    sd = synth.make_weights(d, hid, int(g["wseed"]), 1.0)
+    X, mask = synth.make_table(B, d, seed=int(g["tseed"]))
+    x = (X * (1.0 - mask)).astype(np.float32)
+    rng = np.random.Generator(np.random.Philox(int(g["zseed"])))
+    zs = rng.standard_normal(B, dtype=np.float32)
+    zn = rng.standard_normal((B, d), dtype=np.float32)
+    assert float(x.astype(np.float64).sum()) == float(g["x_sum"])
+    loss, percell, grads = orm.loss_and_grads(sd, x, zs, zn)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    close(percell.mean(1), g["rowloss"], atol=1e-5 * float(g["rowloss"].mean()), rtol=2e-5)
+    s0, s1 = (int(v) for v in g["stride"])
+    for name in orm.LAYERS:
+        ref = g[f"grad__{name}.bias"]
+        assert float(np.abs(grads[f"{name}.bias"] - ref).max()) <= 2e-5 * float(np.abs(ref).max()), name
+        w = grads[f"{name}.weight"]
+        assert float(np.abs(w[::s0, ::s1] - g[f"gsample__{name}.weight"]).max()) <= 2e-5 * float(g[f"gmax__{name}.weight"]), name
+        norm = float(np.sqrt((w.astype(np.float64) ** 2).sum()))
+        assert abs(norm - float(g[f"gnorm__{name}.weight"])) <= 1e-5 * float(g[f"gnorm__{name}.weight"]), name
