@@ -12,6 +12,7 @@
 #include "dp_gemm_bf16.h"
 #include "dp_gemm_bf16_pp.h"
 #include "dp_gemm_bf16_ws.h"
+#include "dp_gemm_bf16_ws2.h"
 #include "dp_gemm_bf16_w4.h"
 #include "dp_gemm_f32.h"
 #include "dp_philox.h"
@@ -235,6 +236,22 @@ static int launch_bf16_ws(const bf16_t* A, const bf16_t* W, const float* bias, v
     return DP_OK;
 }
 
+// K = 256, bf16 output: the weight-stationary kernel with its K loop in asm (dp_gemm_bf16_ws2.h)
+static int launch_bf16_ws2(const bf16_t* A, const bf16_t* W, const float* bias, void* out, int ldo, int64_t M, int N, int act, hipStream_t st) {
+    const DeviceState* ds = device_state_bf16();
+    if (!ds) return DP_EHIP;
+    const int nbn = N / WS2_BN;
+    const int64_t n_rg64 = M / WS2_ROWS;
+    if (n_rg64 > 0x7fffffff) return fail(DP_EINVAL, "GEMM too tall");
+    const int n_rg = (int)n_rg64;
+    const int slots = std::max(1, std::min(ds->num_cus / nbn, ceil_div(n_rg, 8)));
+    const int grid = slots * nbn;
+    if (act) hipLaunchKernelGGL((k_gemm_bf16_ws2<true>), dim3(grid), dim3(WS2_THREADS), WS2_LDS_TOTAL, st, A, W, bias, (bf16_t*)out, ldo, nbn, n_rg);
+    else hipLaunchKernelGGL((k_gemm_bf16_ws2<false>), dim3(grid), dim3(WS2_THREADS), WS2_LDS_TOTAL, st, A, W, bias, (bf16_t*)out, ldo, nbn, n_rg);
+    DP_LAUNCH_CHECK("k_gemm_bf16_ws2");
+    return DP_OK;
+}
+
 // One-time set-up of device `dev` (current on the calling thread): see DeviceState.
 static int ensure_device_ready(int dev) {
     std::lock_guard<std::mutex> lock(g_dev_mutex);
@@ -276,6 +293,8 @@ static int ensure_device_ready(int dev) {
     DP_ATTR((k_gemm_bf16_ws<KT, true, true>), ws_lds_bytes(KT));                                  \
     DP_ATTR((k_gemm_bf16_ws<KT, false, true>), ws_lds_bytes(KT))
     DP_ATTR_WS(1); DP_ATTR_WS(2); DP_ATTR_WS(3); DP_ATTR_WS(4);
+    DP_ATTR((k_gemm_bf16_ws2<true>), WS2_LDS_TOTAL);
+    DP_ATTR((k_gemm_bf16_ws2<false>), WS2_LDS_TOTAL);
 #undef DP_ATTR_WS
 #undef DP_ATTR
     // this device's copy of the scratch array: from here on host code uses d.scratch, never the array's name
@@ -288,12 +307,13 @@ static int ensure_device_ready(int dev) {
 
 // Which kernel runs act(A W^T + b) of shape [*, K] -> [*, N]: ONE predicate, used by gemm() and by dp_plan_gemm_kernel
 // (bench.py labels its roofline with what actually ran).
-enum GemmKernel { GK_F32, GK_WS, GK_W4, GK_PP, GK_SIMPLE, GK_NARROW128, GK_NARROW256, GK_NONE };
+enum GemmKernel { GK_F32, GK_WS, GK_WS2, GK_W4, GK_PP, GK_SIMPLE, GK_NARROW128, GK_NARROW256, GK_NONE };
 static GemmKernel pick_gemm(int dtype, int N, int K, int out_f32) {
     if (dtype == DP_DTYPE_F32) return GK_F32;
     if (dtype != DP_DTYPE_BF16) return GK_NONE;
     const int ws = tune(g_ws_gemm), variant = tune(g_gemm_variant);
-    if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws >= 2) && variant >= 2) return GK_WS;
+    if (N % 256 == 0 && K == 256 && !out_f32 && ws == 3 && variant >= 2) return GK_WS2;
+    if (N % 256 == 0 && (K <= 128 ? ws >= 1 : K <= 256 && ws == 2) && variant >= 2) return GK_WS;
     if (N % 256 == 0 && N <= W4_MAX_N && K >= tune(g_w4_min_k) && K % 128 == 0 && !out_f32 && variant == 3) return GK_W4;
     if (N % 256 == 0 && K >= 3 * PP_BK && variant >= 2) return GK_PP;
     if (N % 256 == 0) return GK_SIMPLE;
@@ -303,6 +323,7 @@ static const char* gemm_kernel_name(GemmKernel k) {
     switch (k) {
         case GK_F32: return "k_gemm_f32";
         case GK_WS: return "k_gemm_bf16_ws";
+        case GK_WS2: return "k_gemm_bf16_ws2";
         case GK_W4: return "k_gemm_bf16_w4";
         case GK_PP: return "k_gemm_bf16_pp";
         case GK_SIMPLE: return "k_gemm_bf16<256,256>";
@@ -320,6 +341,7 @@ static int gemm(int dtype, const void* A, const void* W, const float* bias, void
         const bf16_t *a = (const bf16_t*)A, *w = (const bf16_t*)W;
         switch (pick_gemm(dtype, N, K, out_f32)) {
             case GK_WS: return launch_bf16_ws(a, w, bias, out, ldo, M, N, K, act, out_f32, st);
+            case GK_WS2: return launch_bf16_ws2(a, w, bias, out, ldo, M, N, act, st);
             case GK_W4: return launch_bf16_w4(a, w, bias, out, ldo, M, N, K, act, st, clk);
             case GK_PP: return launch_bf16_pp(a, w, bias, out, ldo, M, N, K, act, out_f32, st, nullptr, clk);
             case GK_SIMPLE: return launch_bf16_cfg<256, 256, 2, 4>(a, w, bias, out, ldo, M, N, K, act, out_f32, st);
@@ -978,7 +1000,7 @@ int dp_tune(const char* key, int value) {
         return DP_OK;
     }
     if (!strcmp(key, "ws_gemm")) {
-        if (value < 0 || value > 2) return fail(DP_EINVAL, "ws_gemm must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(DP_EINVAL, "ws_gemm must be 0, 1, 2 or 3");
         g_ws_gemm = value;
         return DP_OK;
     }

@@ -211,7 +211,8 @@ int dp_linear(int dtype, const void* A, const void* W, const float* bias, void* 
  *                   streams its own rows, no barrier after set-up, one wave's SiLU epilogue under its SIMD partner's MFMAs):
  *                   1 (default) = layers with K <= 128 (the folded proj+mlp.0 layer of tables up to 128 columns: 55 -> 31 us
  *                   per 32 768 x 2048 launch at K = 64), 2 = K <= 256 as well (on par with the ping-pong kernel there),
- *                   0 = never.  Bit-identical results.
+ *                   3 = as 2, with K = 256 on the variant whose K loop is inline assembly (dp_gemm_bf16_ws2.h; also on
+ *                   par: DESIGN.md section 4), 0 = never.  Bit-identical results.
  *   "fuse_mid"      1 (default) = for bf16 plans with d_in = 256 the arithmetic after a Heun iteration's first evaluation
  *                   (diffusion_utils.py:100-101) runs in the epilogue of the mlp.6 GEMM instead of a kernel of its own;
  *                   bit-identical results.

@@ -73,7 +73,8 @@ def test_linear_bf16(M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K", [(16384, 2048, 256), (256 * 33, 2048, 192), (256 * 70, 1024, 512), (256 * 3, 256, 1024),
                                    (256 * 35, 2048, 64), (256, 256, 128), (256 * 9, 512, 256), (256 * 131, 1024, 64),
-                                   (256 * 67, 2048, 2048), (256 * 131, 1024, 2048), (256, 4096, 1152), (256 * 40, 2048, 1024)])
+                                   (256 * 67, 2048, 2048), (256 * 131, 1024, 2048), (256, 4096, 1152), (256 * 40, 2048, 1024),
+                                   (256, 256, 256), (256 * 5, 1024, 256), (32768, 2048, 256), (256 * 129, 2048, 256)])
 def test_linear_bf16_persistent(M, N, K):
     """The persistent kernels beyond one tile per workgroup: whole rounds, a ragged last round, fewer tiles than CUs --
     the four-wave kernel (bf16 output, K >= 1024: "gemm_variant" 3, the default), the ping-pong kernel (K >= 192; float32
@@ -100,6 +101,11 @@ def test_linear_bf16_persistent(M, N, K):
         if 192 <= K <= 256:                                          # both persistent kernels take these shapes
             _lib.check(lib.dp_tune(b"ws_gemm", 0), "dp_tune")
             assert torch.equal(linear(A, W, b, act=True), outs[2])
+        if K == 256:                                                 # the weight-stationary kernel with its K loop in asm
+            _lib.check(lib.dp_tune(b"ws_gemm", 3), "dp_tune")
+            assert torch.equal(linear(A, W, b, act=True), outs[1]), "k_gemm_bf16_ws2 <SiLU>"
+            assert torch.equal(linear(A, W, b, act=False), outs[(1, "noact")]), "k_gemm_bf16_ws2"
+            assert torch.equal(linear(A, W, b, act=True, out_f32=True), outs[(1, "f32")])      # float32 output: not its case
         if K >= 256 and K % 128 == 0 and N <= 4096:                  # the four-wave kernel on its shortest K loops (4, 8 K-tiles)
             _lib.check(lib.dp_tune(b"gemm_variant", 3), "dp_tune")
             _lib.check(lib.dp_tune(b"ws_gemm", 0), "dp_tune")

@@ -19,11 +19,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=32768)
 ap.add_argument("--n", type=int, default=2048)
 ap.add_argument("--k", type=int, default=256)
+ap.add_argument("--ws", type=int, default=2, help="dp_tune ws_gemm: 2 = k_gemm_bf16_ws, 3 = k_gemm_bf16_ws2 (K = 256)")
 a = ap.parse_args()
 _lib.LIB_PATH = os.environ.get("DP_DIAG_LIB", "tools/diag/libdp_ws_stamp.so")
 _lib.SIGNATURES["dp_debug_stamps"] = (C.c_int, [C.c_void_p])
 lib = _lib.load()
-_lib.check(lib.dp_tune(b"ws_gemm", 2), "dp_tune")      # K = 192 / 256 too
+_lib.check(lib.dp_tune(b"ws_gemm", a.ws), "dp_tune")      # 2: K = 192 / 256 too on the weight-stationary kernel; 3: its asm form
 from diffputer_amd.sampler import linear            # noqa: E402
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
