@@ -1022,6 +1022,20 @@ int dp_tune(const char* key, int value) {
     return fail(DP_EINVAL, "unknown tuning key '%s'", key);
 }
 
+// Launch shape of the two prep reductions (dp_prep.h): grid.y = chunks of 256 units, grid.x = row slabs, ~2048 blocks in all
+// (8 per CU: full occupancy) but no slab shorter than 32 iterations of its block (every block ends in atomics).
+struct PrepGrid { dim3 grid; int rows_per_block, vec; };
+static PrepGrid prep_grid(int64_t n_rows, int d, bool vec4) {
+    PrepGrid g;
+    g.vec = vec4 ? 4 : 1;
+    const int units = d / g.vec, by = ceil_div(units, 256);
+    const int rpi = 256 / std::min(units, 256);
+    const int64_t bx = std::max<int64_t>(1, std::min<int64_t>(ceil_div<int64_t>(n_rows, (int64_t)32 * rpi), 2048 / by));
+    g.rows_per_block = (int)ceil_div<int64_t>(n_rows, bx);
+    g.grid = dim3((unsigned)ceil_div<int64_t>(n_rows, g.rows_per_block), (unsigned)by);
+    return g;
+}
+
 int dp_masked_mean_std(const float* X, const uint8_t* mask, int64_t n_rows, int d, float* mean, float* std_out, void* workspace,
                        size_t workspace_bytes, void* stream) {
     if (!X || !mask || !mean || !std_out || !workspace) return fail(DP_EINVAL, "NULL argument");
@@ -1030,14 +1044,14 @@ int dp_masked_mean_std(const float* X, const uint8_t* mask, int64_t n_rows, int 
     hipStream_t st = (hipStream_t)stream;
     double* acc = (double*)workspace;
     double* cnt = acc + d;
-    DP_HIP(hipMemsetAsync(workspace, 0, (size_t)2 * d * sizeof(double), st));
-    const int rows_per_block = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div<int64_t>(n_rows, 2048), 1 << 20));
-    const int blocks = (int)ceil_div<int64_t>(n_rows, rows_per_block);
-    const size_t lds = (size_t)2 * d * sizeof(double);
+    const int replicas = (int)std::min<size_t>(32, workspace_bytes / ((size_t)2 * d * sizeof(double)));
+    DP_HIP(hipMemsetAsync(workspace, 0, (size_t)replicas * 2 * d * sizeof(double), st));
+    const PrepGrid g = prep_grid(n_rows, d, ((uintptr_t)X & 15) == 0 && ((uintptr_t)mask & 3) == 0 && d % 4 == 0);
     for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(k_col_stats, dim3(blocks), dim3(256), lds, st, X, mask, n_rows, d, pass, (const float*)mean, acc, cnt, rows_per_block);
+        if (g.vec == 4) hipLaunchKernelGGL(k_col_stats<4>, g.grid, dim3(256), 0, st, X, mask, n_rows, d, pass, (const float*)mean, acc, cnt, g.rows_per_block, replicas);
+        else hipLaunchKernelGGL(k_col_stats<1>, g.grid, dim3(256), 0, st, X, mask, n_rows, d, pass, (const float*)mean, acc, cnt, g.rows_per_block, replicas);
         DP_LAUNCH_CHECK("k_col_stats");
-        hipLaunchKernelGGL(k_col_finish, dim3(ceil_div(d, 256)), dim3(256), 0, st, d, pass, acc, (const double*)cnt, pass == 0 ? mean : std_out);
+        hipLaunchKernelGGL(k_col_finish, dim3(ceil_div(d, 256)), dim3(256), 0, st, d, pass, acc, replicas, pass == 0 ? mean : std_out);
         DP_LAUNCH_CHECK("k_col_finish");
     }
     return DP_OK;
@@ -1046,10 +1060,13 @@ int dp_masked_mean_std(const float* X, const uint8_t* mask, int64_t n_rows, int 
 int dp_masked_errors(const float* pred, const float* truth, const uint8_t* mask, int64_t n_rows, int d, int ld_mask, int num_num,
                      double* sums, void* stream) {
     if (!pred || !truth || !mask || !sums) return fail(DP_EINVAL, "NULL argument");
-    if (n_rows <= 0 || d < 1 || num_num < 1 || num_num > d || ld_mask < num_num) return fail(DP_EINVAL, "need n_rows > 0, 1 <= num_num <= d, ld_mask >= num_num");
+    if (n_rows <= 0 || d < 1 || d > 4096 || num_num < 1 || num_num > d || ld_mask < num_num) return fail(DP_EINVAL, "need n_rows > 0, 1 <= num_num <= d <= 4096, ld_mask >= num_num");
     hipStream_t st = (hipStream_t)stream;
     DP_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), st));
-    hipLaunchKernelGGL(k_masked_errors, dim3(grid_for(n_rows * d)), dim3(256), 0, st, pred, truth, mask, n_rows * d, d, ld_mask, num_num, sums);
+    const bool vec = (((uintptr_t)pred | (uintptr_t)truth) & 15) == 0 && ((uintptr_t)mask & 3) == 0 && d % 4 == 0 && ld_mask % 4 == 0 && num_num % 4 == 0;
+    const PrepGrid g = prep_grid(n_rows, d, vec);
+    if (g.vec == 4) hipLaunchKernelGGL(k_masked_errors<4>, g.grid, dim3(256), 0, st, pred, truth, mask, n_rows, d, ld_mask, num_num, sums, g.rows_per_block);
+    else hipLaunchKernelGGL(k_masked_errors<1>, g.grid, dim3(256), 0, st, pred, truth, mask, n_rows, d, ld_mask, num_num, sums, g.rows_per_block);
     DP_LAUNCH_CHECK("k_masked_errors");
     return DP_OK;
 }

@@ -28,7 +28,7 @@ def masked_mean_std(X: torch.Tensor, mask: torch.Tensor):
     n, d = X.shape
     mean = torch.empty(d, dtype=torch.float32, device=X.device)
     std = torch.empty(d, dtype=torch.float32, device=X.device)
-    ws = torch.empty(2 * d, dtype=torch.float64, device=X.device)
+    ws = torch.empty(32 * 2 * d, dtype=torch.float64, device=X.device)        # 32 copies of the partial sums (include/diffputer.h)
     with torch.cuda.device(X.device):
         rc = lib.dp_masked_mean_std(X.data_ptr(), m.data_ptr(), n, d, mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                     _stream(X.device))

@@ -223,7 +223,8 @@ int dp_tune(const char* key, int value);
  * Masked column statistics on the device.  Replaces: mean_std(data, mask) (dataset.py:161-169) as main.py:55 calls it:
  * per column, mean and (population) std over the OBSERVED cells (mask == 0); a column with no observed cell gets
  * count 1 like the reference (:164).  X [n_rows, d] float32 row-major, mask [n_rows, d] uint8, mean/std_out [d] float32
- * device pointers; workspace >= 2*d*8 bytes of device memory.  Asynchronous on `stream`.
+ * device pointers; workspace >= 2*d*8 bytes of device memory, 8-byte aligned (up to 32 times that is used when given: the
+ * blocks' partial sums are then spread over as many copies, which shortens the chains of atomics).  Asynchronous on `stream`.
  */
 int dp_masked_mean_std(const float* X, const uint8_t* mask, int64_t n_rows, int d, float* mean, float* std_out,
                        void* workspace, size_t workspace_bytes, void* stream);

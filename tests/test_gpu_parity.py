@@ -590,6 +590,61 @@ def test_device_prep_and_scoring_golden():
     assert torch.allclose(mean_w, ref_mean, rtol=1e-4, atol=1e-6) and torch.allclose(std_w, ref_std, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,d", [(5000, 64), (777, 9), (1201, 51), (300, 1100), (64, 2052), (1, 4), (40000, 256)])
+def test_prep_reductions_every_path(n, d):
+    """dp_masked_mean_std / dp_masked_errors through the C ABI against float64 numpy: the 16-byte path (d % 4 == 0) and
+    the scalar one, more than 256 units per row (several column chunks), a single row, pointers that are not 16-byte
+    aligned (a view one float into a buffer), the smallest workspace the header allows (one copy of the partial sums),
+    a mask wider than the table (ld_mask) and a score over the first num_num columns only."""
+    import ctypes as C
+    from diffputer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n * 31 + d)
+    X = (rng.standard_normal((n, d)) * 3 + 1.5).astype(np.float32)
+    T = (X + 0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    m = rng.random((n, d)) < 0.3
+    obs = ~m
+    cnt = np.maximum(obs.sum(0), 1)
+    mean64 = (X.astype(np.float64) * obs).sum(0) / cnt
+    mean32 = mean64.astype(np.float32)
+    std64 = np.sqrt((((X - mean32).astype(np.float64) ** 2) * obs).sum(0) / cnt)            # float32 subtraction (dataset.py:167)
+    st = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
+
+    def stats(Xd, md, ws):
+        mean = torch.empty(d, device=DEV); std = torch.empty(d, device=DEV)
+        _lib.check(lib.dp_masked_mean_std(Xd.data_ptr(), md.data_ptr(), n, d, mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel() * 8, st), "stats")
+        return mean.cpu().numpy(), std.cpu().numpy()
+
+    Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(m.astype(np.uint8)).to(DEV)
+    for ws in (torch.empty(2 * d, dtype=torch.float64, device=DEV), torch.empty(64 * d, dtype=torch.float64, device=DEV)):
+        mean, std = stats(Xd, md, ws)
+        assert np.array_equal(mean, mean32), np.abs(mean - mean32).max()
+        assert np.allclose(std, std64, rtol=2e-7, atol=0)
+    # the same table one float / one byte into a buffer: the 16-byte loads are not allowed, the result must not change
+    bufX = torch.empty(n * d + 1, device=DEV); bufX[1:] = Xd.reshape(-1)
+    bufm = torch.empty(n * d + 1, dtype=torch.uint8, device=DEV); bufm[1:] = md.reshape(-1)
+    mean_u, std_u = stats(bufX[1:], bufm[1:], torch.empty(64 * d, dtype=torch.float64, device=DEV))
+    assert np.array_equal(mean_u, mean32) and np.allclose(std_u, std64, rtol=2e-7, atol=0)
+
+    def errors(num_num, ld):
+        mw = np.zeros((n, ld), np.uint8); mw[:, :d] = m
+        mw[:, d:] = 1                                                                    # columns past the table must not count
+        mwd = torch.from_numpy(mw).to(DEV)
+        sums = torch.empty(3, dtype=torch.float64, device=DEV)
+        _lib.check(lib.dp_masked_errors(Xd.data_ptr(), torch.from_numpy(T).to(DEV).data_ptr(), mwd.data_ptr(), n, d, ld, num_num, sums.data_ptr(), st), "errors")
+        diff = (X - T)[:, :num_num].astype(np.float64)
+        sel = m[:, :num_num]
+        want = np.array([np.abs(diff[sel]).sum(), (diff[sel] ** 2).sum(), sel.sum()])
+        got = sums.cpu().numpy()
+        assert got[2] == want[2] and np.allclose(got[:2], want[:2], rtol=1e-12, atol=1e-300), (got, want)
+
+    errors(d, d)
+    errors(d, d + 1)
+    errors(max(1, d - 3), d)
+    if d >= 8:
+        errors(d - d % 4 - 4, d + 4)
+
+
 def test_column_major_table_and_out_validation():
     """A pandas-derived (column-major) table must give the result of its row-major copy; a strided `out` is refused."""
     from diffputer_amd import estep
