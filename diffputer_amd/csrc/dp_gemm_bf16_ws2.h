@@ -33,7 +33,7 @@ constexpr int WS2_STAGE_WAVE = 2048;                             // epilogue tra
 constexpr int WS2_BIAS_OFF = WS2_W_BYTES + 8 * WS2_STAGE_WAVE;
 constexpr int WS2_TICKET_OFF = WS2_BIAS_OFF + WS2_BN * 4;
 constexpr int WS2_LDS_TOTAL = WS2_TICKET_OFF + 16;
-#ifdef WS2_DIAG_NOSTORE                                          /* timing-only diagnostic (tools/build_diag.sh): results are not stored */
+#if defined(WS2_DIAG_NOSTORE) || defined(WS2_DIAG_NOEPI)         /* timing-only diagnostics (tools/build_diag.sh): results are not stored */
 constexpr int WS2_NST = 0;
 #else
 constexpr int WS2_NST = 16;                                      // global stores one wave's epilogue issues per row group
@@ -223,11 +223,17 @@ __global__ __launch_bounds__(WS2_THREADS) void k_gemm_bf16_ws2(const bf16_t* __r
         if ((STEP) < 7) { WS2_EPI_WRITE(); }                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
     } while (0)
+#ifdef WS2_DIAG_NOEPI                                            /* timing-only diagnostic: K loops only */
+        if (false) {
+#else
+        {
+#endif
         WS2_EPI_BIAS(0);
         WS2_EPI_COMPUTE(0, 0);
         WS2_EPI_WRITE();
         WS2_EPI_STEP(0); WS2_EPI_STEP(1); WS2_EPI_STEP(2); WS2_EPI_STEP(3);
         WS2_EPI_STEP(4); WS2_EPI_STEP(5); WS2_EPI_STEP(6); WS2_EPI_STEP(7);
+        }
 #undef WS2_EPI_STEP
 #undef WS2_EPI_WRITE
 #undef WS2_EPI_COMPUTE

@@ -14,3 +14,5 @@ mkdir -p tools/diag
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/diag/issue_probe tools/issue_probe.hip
 # SiLU formulations for the GEMM epilogues: cycles per value and accuracy
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/diag/silu_probe tools/silu_probe.hip
+# which instruction classes of one wave make progress under its SIMD partner's MFMA stream
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/diag/overlap_probe tools/overlap_probe.hip

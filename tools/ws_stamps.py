@@ -20,6 +20,8 @@ ap.add_argument("--m", type=int, default=32768)
 ap.add_argument("--n", type=int, default=2048)
 ap.add_argument("--k", type=int, default=256)
 ap.add_argument("--ws", type=int, default=2, help="dp_tune ws_gemm: 2 = k_gemm_bf16_ws, 3 = k_gemm_bf16_ws2 (K = 256)")
+ap.add_argument("--act", type=int, default=1)
+ap.add_argument("--timeline", type=int, default=-1, help="print every stamp of this workgroup's waves, cycles from the workgroup's first stamp")
 a = ap.parse_args()
 _lib.LIB_PATH = os.environ.get("DP_DIAG_LIB", "tools/diag/libdp_ws_stamp.so")
 _lib.SIGNATURES["dp_debug_stamps"] = (C.c_int, [C.c_void_p])
@@ -34,10 +36,10 @@ b = torch.randn(a.n, device=dev, generator=g)
 grid = torch.cuda.get_device_properties(0).multi_processor_count
 buf = torch.zeros(grid * 8 * 16 * 4, dtype=torch.int64, device=dev)
 for _ in range(20):
-    linear(A, W, b, act=True)
+    linear(A, W, b, act=bool(a.act))
 torch.cuda.synchronize()
 _lib.check(lib.dp_debug_stamps(buf.data_ptr()), "dp_debug_stamps")
-linear(A, W, b, act=True)
+linear(A, W, b, act=bool(a.act))
 torch.cuda.synchronize()
 s = buf.cpu().numpy().reshape(grid, 8, 16, 4).astype(np.int64)
 used = s[..., 1] > 0
@@ -50,3 +52,12 @@ for i in range(n_rg):
         print(f"  rg {i} {name}: start {np.median(start[:, w]):8.0f}  K loop {np.median(kl[:, w]):7.0f}  epilogue {np.median(ep[:, w]):7.0f}")
 end = s[:, :, n_rg - 1, 3] - t0
 print(f"  wave lifetime: median {np.median(end):.0f} max {end.max():.0f} cycles")
+if a.timeline >= 0:
+    w = s[a.timeline]
+    base = w[:, 0, 0].min()
+    for wave in range(8):
+        row = [f"t0 {w[wave, 0, 0] - base:6d}"]
+        for i in range(16):
+            if w[wave, i, 1] > 0:
+                row.append(f"[K {w[wave, i, 1] - base:6d} E {w[wave, i, 2] - base:6d} end {w[wave, i, 3] - base:6d}]")
+        print(f"  wave {wave}: " + " ".join(row))
