@@ -170,6 +170,66 @@ __global__ __launch_bounds__(512) void probe(int mfma_iters, int partner_iters, 
     if (s == 12345.678f) sink[0] = s;
 }
 
+// ONE wave per SIMD: per MFMA pair, behind the MFMAs, a slice of epilogue work of the SAME wave (a software-pipelined kernel).
+//   SL 0 nothing   1 two transcendentals   2 two v_accvgpr_read   3 two full-rate VALU   4 one value's whole slice: 1 accread,
+//   1 exp, 1 rcp, 2.5 VALU (alternating 2 / 3)   5 as 4 plus one ds_read_b128 into a ring (the W fragment) with lgkmcnt(7)
+template <int SL>
+__global__ __launch_bounds__(256) void probe_same(int iters, unsigned long long* cyc, float* sink) {
+    __shared__ __attribute__((aligned(16))) char lds[16384];
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ag;
+    for (int i = 0; i < 4; ++i) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ag[i]) : "v"(1.0f));
+    bf16x8 a, b, ring[8];
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x & 7); b[i] = (__bf16)1.0f; }
+    for (int i = 0; i < 8; ++i) ring[i] = a;
+    for (int i = threadIdx.x; i < 16384 / 16; i += 256) ((uint4*)lds)[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (threadIdx.x & 63) * 16;
+    float v0 = (float)threadIdx.x * 1e-3f, v1 = 1.0f + v0, x0, x1;
+    f32x2 p = {v0, v1}, q = {v1, v0};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                             // 8 pairs per iteration
+            if (SL == 5) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[(k + 7) & 7]) : "v"(ad), "n"(1024 * (k + 1)));
+                asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+            }
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(SL == 5 ? ring[k] : a), "v"(b));
+            if (SL == 1 || SL >= 4) asm volatile("v_exp_f32 %0, %0" : "+v"(v0));
+            if (SL == 2 || SL >= 4) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(ag[k & 3]));
+            if (SL == 3 || SL >= 4) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(k + 4) & 7]) : "v"(SL == 5 ? ring[k] : a), "v"(b));
+            if (SL == 1 || SL >= 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(v1));
+            if (SL == 2) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(ag[(k + 1) & 3]));
+            if (SL == 3 || SL >= 4) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(q));
+            if (SL >= 4 && (k & 1)) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(q));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+    float sum = v0 + v1 + p[0] + p[1] + q[0] + q[1];
+    if (SL == 2 || SL >= 4) sum += x0;
+    if (SL == 2) sum += x1;
+    for (int i = 0; i < 8; ++i) { float x; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[i][0])); sum += x; }
+    if (SL == 5) for (int i = 0; i < 8; ++i) sum += (float)ring[i][0];
+    if (sum == 12345.678f) sink[0] = sum;
+}
+
+template <int SL>
+static void run_same(int cus, unsigned long long* cyc, float* sink, const char* what) {
+    std::vector<unsigned long long> h(cus * 8);
+    const int N = 4000;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipMemset(cyc, 0, cus * 8 * sizeof(unsigned long long));
+        hipLaunchKernelGGL(probe_same<SL>, dim3(cus), dim3(256), 0, 0, N, cyc, sink);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
+    }
+    hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    printf("same wave, slice %d (%s): %.1f cycles per MFMA pair\n", SL, what, (double)h[0] / N / 8);
+}
+
 template <int KIND, int MV = 0>
 static void run(int cus, unsigned long long* cyc, float* sink, const char* what) {
     std::vector<unsigned long long> h(cus * 8);
@@ -199,6 +259,12 @@ int main() {
     float* sink;
     (void)hipMalloc(&cyc, cus * 8 * sizeof(unsigned long long));
     (void)hipMalloc(&sink, 4);
+    run_same<0>(cus, cyc, sink, "MFMAs only");
+    run_same<1>(cus, cyc, sink, "+ exp, rcp");
+    run_same<2>(cus, cyc, sink, "+ 2 v_accvgpr_read");
+    run_same<3>(cus, cyc, sink, "+ 2 full-rate VALU");
+    run_same<4>(cus, cyc, sink, "+ one value's epilogue: accread, exp, rcp, 2.5 VALU");
+    run_same<5>(cus, cyc, sink, "as 4 + W fragment ring");
     run<0>(cus, cyc, sink, "SiLU mix: pk_mul, exp, add, rcp, pk_mul, add");
     run<1>(cus, cyc, sink, "six full-rate VALU");
     run<2>(cus, cyc, sink, "exp + rcp");
