@@ -148,7 +148,9 @@ __global__ __launch_bounds__(WS2_THREADS) void k_gemm_bf16_ws2(const bf16_t* __r
     __syncthreads();                                             // ... and everyone else's: the only barrier of the kernel
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(af[s][0]), "+v"(af[s][1]));
+#ifndef WS_DIAG_NOSLEEP
     if (wave >= 4) __builtin_amdgcn_s_sleep(32);                 // start the second wave of each SIMD about half a K loop late
+#endif
 
     // epilogue addresses (the transposer of k_gemm_bf16_ws: 16 rows x 128 B per wave, 16-B chunk c of row r at c ^ (r & 7))
     const unsigned stg = lds0 + WS2_W_BYTES + wave * WS2_STAGE_WAVE;
