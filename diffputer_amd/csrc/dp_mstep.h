@@ -119,12 +119,12 @@ __device__ __forceinline__ float ms_cell_in(const MsEmit& e, const MsRow& r, int
 // owns two adjacent columns (8-byte loads, 4-byte bf16-pair stores) of 16 rows; the transposed copy goes through LDS and is
 // written as pairs of adjacent batch rows.
 template <int OP>
-__global__ __launch_bounds__(256) void k_ms_emit(const MsEmit e) {
+__device__ __forceinline__ void ms_emit_tile(const MsEmit& e, const int bx, const int by, const int nbx) {
     __shared__ __attribute__((aligned(8))) float tile[2][64][66];      // [column parity][column pair][row]
     __shared__ float colred[4][128];
     __shared__ double lossred[4];
     const int tid = threadIdx.x, nl = tid & 63, mg = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 128;
+    const int m0 = by * 64, n0 = bx * 128;
     const int n = n0 + 2 * nl;
     float cs0 = 0.f, cs1 = 0.f;
     double lsum = 0.0;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_ms_emit(const MsEmit e) {
         __syncthreads();
         if (mg < 2) {
             const int c = mg * 64 + nl;
-            e.colpart[(size_t)blockIdx.y * e.ld_col + n0 + c] = (colred[0][c] + colred[1][c]) + (colred[2][c] + colred[3][c]);
+            e.colpart[(size_t)by * e.ld_col + n0 + c] = (colred[0][c] + colred[1][c]) + (colred[2][c] + colred[3][c]);
         }
     }
     if (OP == MS_LOSS) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_ms_emit(const MsEmit e) {
         for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
         if (nl == 0) lossred[mg] = lsum;
         __syncthreads();
-        if (tid == 0) e.losspart[blockIdx.y * gridDim.x + blockIdx.x] = (lossred[0] + lossred[1]) + (lossred[2] + lossred[3]);
+        if (tid == 0) e.losspart[by * nbx + bx] = (lossred[0] + lossred[1]) + (lossred[2] + lossred[3]);
     }
     if (e.outT.p) {
         __syncthreads();
@@ -236,6 +236,24 @@ __global__ __launch_bounds__(256) void k_ms_emit(const MsEmit e) {
             ms_exp_store2(e.outT, n0 + nn, m0 + 2 * ml2, t.x, t.y);
         }
     }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_ms_emit(const MsEmit e) { ms_emit_tile<OP>(e, blockIdx.x, blockIdx.y, gridDim.x); }
+
+// The seven weight tensors' operands (as stored and transposed) in ONE launch: they are re-split every step (the optimiser
+// has just changed them) and seven launches of 32 ... 512 tiles each cost ~11 us apiece, mostly ramp-up and tail.
+struct MsEmitGroup {
+    MsEmit e[7];
+    int first[8];           // first[l] = first workgroup of tensor l; first[7] = grid size
+    int nbx[7];             // column blocks of tensor l
+};
+__global__ __launch_bounds__(256) void k_ms_emit_weights(const MsEmitGroup g) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < 7; ++i) l += (int)blockIdx.x >= g.first[i];
+    const int t = blockIdx.x - g.first[l];
+    ms_emit_tile<MS_W>(g.e[l], t % g.nbx[l], t / g.nbx[l], g.nbx[l]);
 }
 
 // grad[n][k] = sum_s part[s][n][k] over the valid extent (the GEMM output is padded to [Np][ld])
@@ -269,6 +287,37 @@ __global__ __launch_bounds__(256) void k_ms_colsum(const float* __restrict__ col
         const float v = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
         out[n] = v;
         if (out2) out2[n] = v;
+    }
+}
+
+// The six bias-gradient reductions of a step in one launch (each emit keeps its own column partials until the end).
+struct MsColGroup {
+    const float* colpart[6];
+    float* out[6];
+    float* out2[6];
+    int N[6], first[7];     // first[j] = first workgroup of reduction j; first[6] = grid size
+    int blocks, ld;
+};
+__global__ __launch_bounds__(256) void k_ms_colsum_group(const MsColGroup g) {
+    __shared__ float red[4][64];
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) j += (int)blockIdx.x >= g.first[i];
+    const int nl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n = (blockIdx.x - g.first[j]) * 64 + nl;
+    const int per = (g.blocks + 3) / 4;
+    const float* __restrict__ cp = g.colpart[j];
+    float a = 0.f;
+    if (n < g.N[j]) {
+#pragma unroll 8
+        for (int b = q * per; b < min(g.blocks, (q + 1) * per); ++b) a += cp[(size_t)b * g.ld + n];
+    }
+    red[q][nl] = a;
+    __syncthreads();
+    if (q == 0 && n < g.N[j]) {
+        const float v = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
+        g.out[j][n] = v;
+        if (g.out2[j]) g.out2[j][n] = v;
     }
 }
 

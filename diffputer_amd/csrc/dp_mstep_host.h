@@ -32,7 +32,7 @@ static void ms_layers(const MsDims& d, MsLayer L[7]) {
 
 struct MsWork {
     MsRow* rc;
-    float *noisy, *emb, *gout, *pre[4], *colpart, *zero;        // pre: at0, a1, a2, a3
+    float *noisy, *emb, *gout, *pre[4], *colpart[6], *zero;     // pre: at0, a1, a2, a3; colpart: one per bias-gradient reduction
     double* losspart;
     bf16_t *uN, *uT, *peN, *peT, *t1N, *t1T, *h0N, *h0T, *h1N, *h1T, *h2N, *h2T, *h3N, *h3T;
     bf16_t *dFN, *dFT, *da3N, *da3T, *da2N, *da2T, *da1N, *da1T, *dh0N, *dh0T, *dat0T;
@@ -54,7 +54,7 @@ static MsWork ms_carve(const MsDims& d, void* base) {
     w.pre[1] = (float*)take((size_t)d.Bp * d.H2p * 4);
     w.pre[2] = (float*)take((size_t)d.Bp * d.H2p * 4);
     w.pre[3] = (float*)take((size_t)d.Bp * d.Hp * 4);
-    w.colpart = (float*)take((size_t)(d.Bp / 64) * maxf * 4);
+    for (int j = 0; j < 6; ++j) w.colpart[j] = (float*)take((size_t)(d.Bp / 64) * maxf * 4);
     w.zero = (float*)take((size_t)maxf * 4);
     w.losspart = (double*)take((size_t)(d.Bp / 64) * (d.Dp / 128) * 8);
     w.uN = expd(d.Bp, d.Dp); w.uT = expd(d.Dp, d.Bp);
@@ -119,12 +119,22 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
 
     auto blank = [&]() { MsEmit e; memset(&e, 0, sizeof e); e.S = 1; return e; };
     // ---- operands that do not depend on the network: weights (as stored: forward; transposed: dX), input, embedding ----
-    for (int l = 0; l < 7; ++l) {
-        MsEmit e = blank();
-        e.src = w[l]; e.ld_src = L[l].K; e.m_valid = L[l].N; e.n_valid = L[l].K;
-        e.outN = {k.WN[l], L[l].Np, L[l].Kp};
-        if (l != 0 && l != 5) e.outT = {k.WT[l], L[l].Kp, L[l].Np};           // proj and time_embed.0 have no input gradient
-        if ((rc = ms_emit<MS_W>(e, L[l].Np, L[l].Kp, st))) return rc;
+    {
+        MsEmitGroup g;
+        int nb = 0;
+        for (int l = 0; l < 7; ++l) {
+            MsEmit e = blank();
+            e.src = w[l]; e.ld_src = L[l].K; e.m_valid = L[l].N; e.n_valid = L[l].K;
+            e.outN = {k.WN[l], L[l].Np, L[l].Kp};
+            if (l != 0 && l != 5) e.outT = {k.WT[l], L[l].Kp, L[l].Np};       // proj and time_embed.0 have no input gradient
+            g.e[l] = e;
+            g.first[l] = nb;
+            g.nbx[l] = L[l].Kp / 128;
+            nb += (L[l].Kp / 128) * (L[l].Np / 64);
+        }
+        g.first[7] = nb;
+        hipLaunchKernelGGL(k_ms_emit_weights, dim3(nb), dim3(256), 0, st, g);
+        DP_LAUNCH_CHECK("k_ms_emit_weights");
     }
     {
         MsEmit e = blank();
@@ -167,16 +177,22 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
         e.S = S; e.src_stride = (size_t)d.Bp * d.Dp;
         e.src = k.gout; e.ld_src = d.Dp; e.bias = b[4]; e.rc = k.rc; e.x = x; e.noisy_in = k.noisy; e.ld_noisy = d.Dp;
         e.m_valid = d.B; e.n_valid = d.D; e.d_valid = d.D; e.scale = (float)(2.0 / ((double)d.B * d.D));
-        e.percell = percell; e.losspart = k.losspart; e.colpart = k.colpart; e.ld_col = maxf;
+        e.percell = percell; e.losspart = k.losspart; e.colpart = k.colpart[0]; e.ld_col = maxf;
         e.outN = {k.dFN, d.Bp, d.Dp}; e.outT = {k.dFT, d.Dp, d.Bp};
         if ((rc = ms_emit<MS_LOSS>(e, d.Bp, d.Dp, st))) return rc;
         hipLaunchKernelGGL(k_ms_loss, dim3(1), dim3(256), 0, st, (const double*)k.losspart, nlb, 1.0 / ((double)d.B * d.D), loss);
         DP_LAUNCH_CHECK("k_ms_loss");
     }
-    auto bias_grad = [&](int l, float* second) -> int {
-        hipLaunchKernelGGL(k_ms_colsum, dim3(ceil_div(L[l].N, 64)), dim3(256), 0, st, (const float*)k.colpart, d.Bp / 64, maxf, gb[l], second, L[l].N);
-        DP_LAUNCH_CHECK("k_ms_colsum");
-        return DP_OK;
+    // bias gradients = column sums of the dY each emit leaves as per-64-row partials; reduced together at the end
+    MsColGroup cg;
+    memset(&cg, 0, sizeof cg);
+    cg.blocks = d.Bp / 64; cg.ld = maxf;
+    int ncol = 0, colblocks = 0;
+    auto bias_grad = [&](int l, float* second) {                 // the reduction of the most recently written partials
+        cg.colpart[ncol] = k.colpart[ncol]; cg.out[ncol] = gb[l]; cg.out2[ncol] = second; cg.N[ncol] = L[l].N;
+        cg.first[ncol] = colblocks;
+        colblocks += ceil_div(L[l].N, 64);
+        ++ncol;
     };
     // weight gradient of layer l: dW[n][k] = sum_b dYt[n][b] Xt[k][b].  (Tried: these products on a second stream, so that they
     // fill the ramp-up and tail of the input-gradient chain -- no gain: a persistent GEMM holds every CU's LDS until its tiles
@@ -199,30 +215,33 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
         MsEmit e = blank();
         e.S = S; e.src_stride = (size_t)d.Bp * L[l].Kp;
         e.src = k.gout; e.ld_src = L[l].Kp; e.m_valid = d.Bp; e.n_valid = L[l].K; e.pre_in = pre; e.ld_pre = L[l].Kp;
-        e.colpart = k.colpart; e.ld_col = maxf;
+        e.colpart = k.colpart[ncol]; e.ld_col = maxf;
         if (outN) e.outN = {outN, d.Bp, L[l].Kp};
         if (outT) e.outT = {outT, L[l].Kp, d.Bp};
         return pre ? ms_emit<MS_BWD_ACT>(e, d.Bp, L[l].Kp, st) : ms_emit<MS_BWD_LIN>(e, d.Bp, L[l].Kp, st);
     };
     // ---- backward (what loss.backward() computes, main.py:131) ----
-    if ((rc = bias_grad(4, nullptr))) return rc;                                                   // mlp.6.bias: column sums of dF
+    bias_grad(4, nullptr);                                                   // mlp.6.bias: column sums of dF
     if ((rc = wgrad(4, k.dFT, k.h3T))) return rc;
     if ((rc = xgrad(4, k.dFN, k.pre[3], k.da3N, k.da3T))) return rc;                               // d a3
-    if ((rc = bias_grad(3, nullptr))) return rc;
+    bias_grad(3, nullptr);
     if ((rc = wgrad(3, k.da3T, k.h2T))) return rc;
     if ((rc = xgrad(3, k.da3N, k.pre[2], k.da2N, k.da2T))) return rc;                              // d a2
-    if ((rc = bias_grad(2, nullptr))) return rc;
+    bias_grad(2, nullptr);
     if ((rc = wgrad(2, k.da2T, k.h1T))) return rc;
     if ((rc = xgrad(2, k.da2N, k.pre[1], k.da1N, k.da1T))) return rc;                              // d a1
-    if ((rc = bias_grad(1, nullptr))) return rc;
+    bias_grad(1, nullptr);
     if ((rc = wgrad(1, k.da1T, k.h0T))) return rc;
     if ((rc = xgrad(1, k.da1N, nullptr, k.dh0N, k.dh0T))) return rc;                               // d h0 = d emb
-    if ((rc = bias_grad(0, gb[6]))) return rc;                                                     // proj.bias and time_embed.2.bias
+    bias_grad(0, gb[6]);                                                    // proj.bias and time_embed.2.bias
     if ((rc = wgrad(0, k.dh0T, k.uT))) return rc;
     if ((rc = wgrad(6, k.dh0T, k.t1T))) return rc;
     if ((rc = xgrad(6, k.dh0N, k.pre[0], nullptr, k.dat0T))) return rc;                            // d at0
-    if ((rc = bias_grad(5, nullptr))) return rc;
+    bias_grad(5, nullptr);
     if ((rc = wgrad(5, k.dat0T, k.peT))) return rc;
+    for (int j = ncol; j <= 6; ++j) cg.first[j] = colblocks;
+    hipLaunchKernelGGL(k_ms_colsum_group, dim3(colblocks), dim3(256), 0, st, cg);
+    DP_LAUNCH_CHECK("k_ms_colsum_group");
     return DP_OK;
 }
 
