@@ -25,7 +25,7 @@ def m_step(train_data: torch.Tensor, hid_dim: int, *, max_epochs: int = 10001, b
     weights loaded, best loss).  `train_data` [N, D] float32 on the training device.
 
     native: loss and gradients of a batch from the HIP training step (`mstep.NativeTrainStep`, dp_mstep_fwd_bwd: bf16 hi/lo
-    split GEMMs, ~1e-5 of float32 autograd, 1.5x its speed at H = 1024 / batch 4096) instead of PyTorch autograd; the draws,
+    split GEMMs, ~1e-5 of float32 autograd, 1.7-1.8x its speed at H = 1024 / batch 4096) instead of PyTorch autograd; the draws,
     Adam and the scheduler stay PyTorch's.  Default (None): native on a CUDA device, autograd on CPU."""
     dev = train_data.device
     n, d = train_data.shape
