@@ -87,9 +87,12 @@ static int ms_emit(const MsEmit& e, int Mp, int Np, hipStream_t st) {
 // Split factor of a product with `tiles` 256 x 256 output tiles over a reduction of K columns: enough slices to give every
 // CU a tile (the batch is only 4 096 rows: a [4096, 1024] output is 64 tiles for 256 CUs), each slice a whole number of
 // 256-column blocks.  Partial sums cost memory traffic, so no more slices than that.
+#ifndef MS_SPLIT_THRESH
+#define MS_SPLIT_THRESH 192
+#endif
 static int ms_split(int tiles, int K) {
     int S = 1;
-    while (tiles * S < 192 && K % (512 * S) == 0 && S < 16) S *= 2;
+    while (tiles * S < MS_SPLIT_THRESH && K % (512 * S) == 0 && S < 16) S *= 2;
     return S;
 }
 
