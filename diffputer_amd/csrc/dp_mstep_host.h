@@ -199,7 +199,9 @@ static int mstep_fwd_bwd(int d_in, int hid, int64_t batch, const float* x, const
     };
     // weight gradient of layer l: dW[n][k] = sum_b dYt[n][b] Xt[k][b].  (Tried: these products on a second stream, so that they
     // fill the ramp-up and tail of the input-gradient chain -- no gain: a persistent GEMM holds every CU's LDS until its tiles
-    // are done, so the chain's next kernel waits for it just the same; tools/mstep_bench.py 1.487 vs 1.498 ms.)
+    // are done, so the chain's next kernel waits for it just the same; tools/mstep_bench.py 1.487 vs 1.498 ms.  Also tried: only the
+    // small reduction below on a side stream, beside the next product, with a partials buffer of its own: 1.34 -> 1.42 ms -- the
+    // fork / join events cost more than the 12 us kernel they hide.)
     auto wgrad = [&](int l, const bf16_t* dYT, const bf16_t* XT) -> int {
         int S = 1;
         int r = ms_gemm(dYT, XT, k.gout, k.zero, L[l].Np, L[l].Kp, d.Bp, st, &S);
