@@ -73,6 +73,63 @@ __device__ __forceinline__ void partner_iter(float& v0, float& v1, f32x2& p, f32
         r = r * (two - d * r);
         p = x * r + (f32x2){1e-3f, 1e-3f};
         asm volatile("" : "+v"(p));
+    } else if (KIND == 8) {
+        // as kind 7 with the accumulator reads in the gap, ahead of the VALU burst: [16 accread][40 VALU][16 exp][16 rcp]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a, b, c, d;
+            asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "a"(ag[0]), "a"(ag[1]), "a"(ag[2]), "a"(ag[3]));
+            asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d));
+        }
+        f32x2 w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = p + q * (float)k;
+#pragma unroll
+        for (int rep = 0; rep < 5; ++rep)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(w[k]) : "v"(q));
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = w[k & 7][k >> 3];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("v_exp_f32 %0, %0" : "+v"(t[k]));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("v_rcp_f32 %0, %0" : "+v"(t[k]));
+        float acc2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc2 += t[k];
+        asm volatile("" : "+v"(acc2));
+        p.x = acc2 * 1e-30f + 1.0f; p.y = 1.0f;
+    } else if (KIND == 7) {
+        // one slot of a stage-major epilogue: a burst of 40 independent-enough VALU instructions, then 32 transcendentals
+        // and 16 accumulator reads (called 4x per iteration by the harness: the harness' "4 units" = 4 slots)
+        f32x2 w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = p + q * (float)k;
+#pragma unroll
+        for (int rep = 0; rep < 5; ++rep)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(w[k]) : "v"(q));
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = w[k & 7][k >> 3];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("v_exp_f32 %0, %0" : "+v"(t[k]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a, b, c, d;
+            asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "a"(ag[0]), "a"(ag[1]), "a"(ag[2]), "a"(ag[3]));
+            asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("v_rcp_f32 %0, %0" : "+v"(t[k]));
+        float acc2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc2 += t[k];
+        asm volatile("" : "+v"(acc2));
+        p.x = acc2 * 1e-30f + 1.0f; p.y = 1.0f;
     } else if (KIND == 6) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -148,6 +205,13 @@ __global__ __launch_bounds__(512) void probe(int mfma_iters, int partner_iters, 
                     for (int q2 = 0; q2 < 4; ++q2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k + q2]) : "v"(a), "v"(b));
                     asm volatile("s_nop %0" ::"n"(MV - 40));
                 }
+            }
+        } else if (MV >= 60 && MV < 70) {                         // 32 MFMAs, then (MV - 60) x s_nop 15
+            for (int it = 0; it < mfma_iters; it += 4) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k & 7]) : "v"(a), "v"(b));
+#pragma unroll
+                for (int g = 0; g < MV - 60; ++g) asm volatile("s_nop 15");
             }
         } else if (MV == 3) {                                     // 16x16x32 with one idle issue slot behind every MFMA
             for (int it = 0; it < mfma_iters; ++it) {
@@ -295,6 +359,17 @@ int main() {
     run<1, 51>(cus, cyc, sink, "six full-rate VALU");
     run<1, 55>(cus, cyc, sink, "six full-rate VALU");
     run<0, 47>(cus, cyc, sink, "SiLU mix");
+    printf("stage-major epilogue slots (kind 7: 40 VALU, then 32 transcendentals + 16 accumulator reads; 4 slots per iteration) under 32 MFMAs + g x s_nop 15 (streams 60 + g; 8 MFMAs = a quarter of a segment)\n");
+    run<7, 0>(cus, cyc, sink, "stage-major slot");
+    run<7, 62>(cus, cyc, sink, "stage-major slot");
+    run<7, 63>(cus, cyc, sink, "stage-major slot");
+    run<7, 64>(cus, cyc, sink, "stage-major slot");
+    run<7, 65>(cus, cyc, sink, "stage-major slot");
+    run<7, 66>(cus, cyc, sink, "stage-major slot");
+    run<8, 64>(cus, cyc, sink, "slot, accumulator reads first");
+    run<8, 65>(cus, cyc, sink, "slot, accumulator reads first");
+    run<8, 66>(cus, cyc, sink, "slot, accumulator reads first");
+    run<8, 67>(cus, cyc, sink, "slot, accumulator reads first");
     printf("MFMA stream 10 = stream 0 with the partner at s_setprio 3\n");
     run<1, 10>(cus, cyc, sink, "six full-rate VALU");
     run<0, 10>(cus, cyc, sink, "SiLU mix");
